@@ -1,0 +1,408 @@
+// fs2_attn.hip — fused scaled-dot-product attention with key-padding mask (forward + backward), dk = dv = 128.
+// Reference: transformer/Modules.py:14-25 (bmm, /sqrt(dk), masked_fill(-inf), softmax, bmm) and the head
+// split/merge of transformer/SubLayers.py:39-52.  The S x S score matrix never reaches HBM: online softmax
+// over 32-key tiles, only the per-row log-sum-exp is saved for backward (flash-style).
+//
+// Layout: the fused QKV projection writes one buffer qkv[M][3*H*128] = (q | k | v), head h in columns
+// h*128..h*128+127 of each third; the context is written as ctx[M][H*128] (== the reference's merged
+// (B, S, H*dv) tensor), so no permute/contiguous copy exists anywhere.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact f32): scores are computed TRANSPOSED where that makes the
+// probability tile land directly in the A-operand layout of the following product (C layout: lane = col,
+// regs = rows (r&3)+8*(r>>2)+4*(lane>>5);  A layout: lane = row, k-slot = lane>>5) -> P never leaves registers.
+// Storage dtype T may be bf16; tiles are widened to f32 when staged into LDS (first revision: f32 MFMA rate).
+#include "fs2_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DK 128
+// row r of a [32][128] f32 tile, 16-B chunk c (0..31): XOR-swizzled so ds_read_b128 by 16 distinct rows is conflict-free
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
+__device__ __forceinline__ int crow(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+
+// stage a [32 rows][128] tile (rows row0.., column offset col0 of a ld-strided matrix) into LDS as f32, swizzled.
+// rows >= nrows_valid are zero-filled. 256 threads (or NT threads).
+template <typename T, int NT>
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const T* __restrict__ base, long ld, int row0, int nrows_valid,
+                                           int tid) {
+#pragma unroll
+    for (int i = 0; i < 1024 / NT; ++i) {
+        int idx = tid + NT * i;
+        int r = idx >> 5, c = idx & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nrows_valid) v = ld4<T>(base + (size_t)(row0 + r) * ld + c * 4);
+        *reinterpret_cast<float4*>(lds + swz(r, c)) = v;
+    }
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T>
+__global__ void __launch_bounds__(256, 1) attn_fwd_kernel(const T* __restrict__ qkv, long ld, T* __restrict__ ctx, long ldo,
+                                                          float* __restrict__ lse, const int32_t* __restrict__ lens, int S,
+                                                          int H, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[32 * 512];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[32 * 512];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(lens[b], S) : S;
+    const int q0 = qt * 128;
+    const size_t rowbase = (size_t)b * S;
+    T* out = ctx + rowbase * ldo + h * DK;
+    float* lse_o = lse + ((size_t)b * H + h) * S;
+    if (q0 >= len) {  // fully padded query tile: zeros (the rows are masked to zero downstream anyway)
+        for (int i = tid; i < 128 * 32; i += 256) {
+            int r = i >> 5, c = (i & 31) * 4;
+            if (q0 + r < S) st4<T>(out + (size_t)(q0 + r) * ldo + c, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        if (tid < 128 && q0 + tid < S) lse_o[q0 + tid] = 0.f;
+        return;
+    }
+    const T* Q = qkv + rowbase * ld + h * DK;
+    const T* K = qkv + rowbase * ld + (size_t)H * DK + h * DK;
+    const T* V = qkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+
+    const int myq = q0 + w * 32 + fl;
+    float qf[64];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (myq < S) v = ld4<T>(Q + (size_t)myq * ld + h2 * 64 + u * 4);
+        qf[u * 4 + 0] = v.x * scale; qf[u * 4 + 1] = v.y * scale; qf[u * 4 + 2] = v.z * scale; qf[u * 4 + 3] = v.w * scale;
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (int k0 = 0; k0 < len; k0 += 32) {
+        __syncthreads();
+        stage_tile<T, 256>(sK, K, ld, k0, min(32, S - k0), tid);
+        stage_tile<T, 256>(sV, V, ld, k0, min(32, S - k0), tid);
+        __syncthreads();
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float4 kf = *reinterpret_cast<const float4*>(sK + swz(fl, h2 * 16 + u));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[u * 4 + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[u * 4 + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[u * 4 + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[u * 4 + 3], s, 0, 0, 0);
+        }
+        // s[r] = score(q = lane&31, key = k0 + crow(r,h2))
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (k0 + crow(r, h2) >= len) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mn = fmaxf(m, mx);
+        float alpha = __expf(m - mn);   // m = -inf on the first tile -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mn); rs += s[r]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float ar = __shfl(alpha, crow(r, h2), 64);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int key = crow(r, h2);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                int col = nb * 32 + fl;
+                float vb = *reinterpret_cast<const float*>(sV + swz(key, col >> 2) + (col & 3) * 4);
+                o[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[r], vb, o[nb], 0, 0, 0);
+            }
+        }
+    }
+    float linv = l > 0.f ? 1.f / l : 0.f;
+    if (h2 == 0 && myq < S) lse_o[myq] = (l > 0.f) ? m + __logf(l) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float li = __shfl(linv, crow(r, h2), 64);
+        int q = q0 + w * 32 + crow(r, h2);
+        if (q < S) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) Elem<T>::st(out + (size_t)q * ldo + nb * 32 + fl, o[nb][r] * li);
+        }
+    }
+}
+
+extern "C" int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_t* lens, int B, int S, int H, int dk,
+                            float scale, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(qkv && ctx && lse, "attn_fwd: null pointer");
+    FS2_CHECK_ARG(dk == DK, "attn_fwd: only d_k = 128 is supported (got %d)", dk);
+    FS2_CHECK_ARG(B >= 0 && S > 0 && H > 0, "attn_fwd: bad shape");
+    if (B == 0) return FS2_OK;
+    dim3 grid(fs2_cdiv(S, 128), H, B);
+    long ld = 3L * H * DK, ldo = (long)H * DK;
+    if (dtype == FS2_F32) attn_fwd_kernel<float><<<grid, 256, 0, stream>>>((const float*)qkv, ld, (float*)ctx, ldo, lse, lens, S, H, scale);
+    else if (dtype == FS2_BF16) attn_fwd_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (bf16_t*)ctx, ldo, lse, lens, S, H, scale);
+    else { fs2_set_error("attn_fwd: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_LAUNCH("attn_fwd");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ backward, part 0: D[b,h,q] = sum_d dO*O
+template <typename T>
+__global__ void attn_delta_kernel(const T* __restrict__ ctx, const T* __restrict__ dctx, float* __restrict__ delta, int rows,
+                                  int S, int H) {
+    int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // idx = row*H + h
+    if (idx >= rows * H) return;
+    int lane = threadIdx.x & 63;
+    int row = idx / H, h = idx - row * H;
+    size_t off = (size_t)row * H * DK + h * DK + lane * 2;
+    float s = Elem<T>::ld(ctx + off) * Elem<T>::ld(dctx + off) + Elem<T>::ld(ctx + off + 1) * Elem<T>::ld(dctx + off + 1);
+    s = wave_sum(s);
+    if (lane == 0) {
+        int b = row / S, q = row - b * S;
+        delta[((size_t)b * H + h) * S + q] = s;
+    }
+}
+
+// ------------------------------------------------------------------ backward, part 1: dK, dV
+// One wave owns 32 keys; the block's 4 waves share the streamed Q / dO tiles.
+// dynamic LDS: [4 waves][K 16K | V 16K] + Q 16K + dO 16K = 160 KiB.
+template <typename T>
+__global__ void __launch_bounds__(256, 1) attn_bwd_dkv_kernel(const T* __restrict__ qkv, long ld, const T* __restrict__ dctx,
+                                                              long ldo, const float* __restrict__ lse,
+                                                              const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                              const int32_t* __restrict__ lens, int S, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(lens[b], S) : S;
+    const size_t rowbase = (size_t)b * S;
+    const int kbase = kt * 128 + w * 32;
+    T* dK = dqkv + rowbase * ld + (size_t)H * DK + h * DK;
+    T* dV = dqkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    if (kt * 128 >= len) {   // all keys of this block are padding: gradients are zero
+        for (int i = tid; i < 128 * 32; i += 256) {
+            int r = i >> 5, c = (i & 31) * 4;
+            if (kt * 128 + r < S) {
+                st4<T>(dK + (size_t)(kt * 128 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+                st4<T>(dV + (size_t)(kt * 128 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+        return;
+    }
+    unsigned char* sKw = smem + w * 32768;
+    unsigned char* sVw = sKw + 16384;
+    unsigned char* sQ = smem + 131072;
+    unsigned char* sdO = sQ + 16384;
+    const T* Q = qkv + rowbase * ld + h * DK;
+    const T* K = qkv + rowbase * ld + (size_t)H * DK + h * DK;
+    const T* V = qkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    const T* dO = dctx + rowbase * ldo + h * DK;
+    const float* lse_b = lse + ((size_t)b * H + h) * S;
+    const float* del_b = delta + ((size_t)b * H + h) * S;
+    // each wave stages its own K / V sub-tiles (64 threads)
+    stage_tile<T, 64>(sKw, K, ld, kbase, max(0, min(32, S - kbase)), lane);
+    stage_tile<T, 64>(sVw, V, ld, kbase, max(0, min(32, S - kbase)), lane);
+    const bool key_ok = (kbase + fl) < len;
+
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[nb][r] = 0.f; dv[nb][r] = 0.f; }
+
+    for (int q0 = 0; q0 < len; q0 += 32) {
+        __syncthreads();
+        stage_tile<T, 256>(sQ, Q, ld, q0, min(32, S - q0), tid);
+        stage_tile<T, 256>(sdO, dO, ldo, q0, min(32, S - q0), tid);
+        __syncthreads();
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        // S[q][key] : A = Q (lane row = q), B = K^T (lane col = key)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float4 qa = *reinterpret_cast<const float4*>(sQ + swz(fl, h2 * 16 + u));
+            float4 kb = *reinterpret_cast<const float4*>(sKw + swz(fl, h2 * 16 + u));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kb.x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kb.y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kb.z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kb.w, s, 0, 0, 0);
+        }
+        // dP[q][key] : A = dO, B = V^T
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float4 da = *reinterpret_cast<const float4*>(sdO + swz(fl, h2 * 16 + u));
+            float4 vb = *reinterpret_cast<const float4*>(sVw + swz(fl, h2 * 16 + u));
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da.x, vb.x, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da.y, vb.y, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da.z, vb.z, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da.w, vb.w, dp, 0, 0, 0);
+        }
+        // lane = key (col), reg r = query row crow(r,h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int q = q0 + crow(r, h2);
+            float p = 0.f, ds = 0.f;
+            if (key_ok && q < len) {
+                p = __expf(s[r] * scale - lse_b[q]);
+                ds = p * (dp[r] - del_b[q]) * scale;
+            }
+            s[r] = p; dp[r] = ds;
+        }
+        // dV[key][d] += P^T dO ; dK[key][d] += dS^T Q     (A = regs, lane row = key, k-slot = q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int qr = crow(r, h2);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                int col = nb * 32 + fl;
+                float ob = *reinterpret_cast<const float*>(sdO + swz(qr, col >> 2) + (col & 3) * 4);
+                float qb = *reinterpret_cast<const float*>(sQ + swz(qr, col >> 2) + (col & 3) * 4);
+                dv[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[r], ob, dv[nb], 0, 0, 0);
+                dk[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[r], qb, dk[nb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int key = kbase + crow(r, h2);
+        if (key < S) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                Elem<T>::st(dK + (size_t)key * ld + nb * 32 + fl, dk[nb][r]);
+                Elem<T>::st(dV + (size_t)key * ld + nb * 32 + fl, dv[nb][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward, part 2: dQ
+template <typename T>
+__global__ void __launch_bounds__(256, 1) attn_bwd_dq_kernel(const T* __restrict__ qkv, long ld, const T* __restrict__ dctx,
+                                                             long ldo, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                             const int32_t* __restrict__ lens, int S, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[32 * 512];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[32 * 512];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(lens[b], S) : S;
+    const int q0 = qt * 128;
+    const size_t rowbase = (size_t)b * S;
+    T* dQ = dqkv + rowbase * ld + h * DK;
+    if (q0 >= len) {
+        for (int i = tid; i < 128 * 32; i += 256) {
+            int r = i >> 5, c = (i & 31) * 4;
+            if (q0 + r < S) st4<T>(dQ + (size_t)(q0 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        return;
+    }
+    const T* Q = qkv + rowbase * ld + h * DK;
+    const T* K = qkv + rowbase * ld + (size_t)H * DK + h * DK;
+    const T* V = qkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    const T* dO = dctx + rowbase * ldo + h * DK;
+    const int myq = q0 + w * 32 + fl;
+    const bool q_ok = myq < len;
+    float my_lse = 0.f, my_del = 0.f;
+    if (myq < S) { my_lse = lse[((size_t)b * H + h) * S + myq]; my_del = delta[((size_t)b * H + h) * S + myq]; }
+    float qf[64], df[64];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), d = v;
+        if (myq < S) { v = ld4<T>(Q + (size_t)myq * ld + h2 * 64 + u * 4); d = ld4<T>(dO + (size_t)myq * ldo + h2 * 64 + u * 4); }
+        qf[u * 4 + 0] = v.x; qf[u * 4 + 1] = v.y; qf[u * 4 + 2] = v.z; qf[u * 4 + 3] = v.w;
+        df[u * 4 + 0] = d.x; df[u * 4 + 1] = d.y; df[u * 4 + 2] = d.z; df[u * 4 + 3] = d.w;
+    }
+    f32x16 dq[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[nb][r] = 0.f;
+
+    for (int k0 = 0; k0 < len; k0 += 32) {
+        __syncthreads();
+        stage_tile<T, 256>(sK, K, ld, k0, min(32, S - k0), tid);
+        stage_tile<T, 256>(sV, V, ld, k0, min(32, S - k0), tid);
+        __syncthreads();
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        // S^T[key][q] : A = K (lane row = key), B = Q^T (lane col = q) ; dP^T[key][q] : A = V, B = dO^T
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float4 ka = *reinterpret_cast<const float4*>(sK + swz(fl, h2 * 16 + u));
+            float4 va = *reinterpret_cast<const float4*>(sV + swz(fl, h2 * 16 + u));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qf[u * 4 + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qf[u * 4 + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qf[u * 4 + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qf[u * 4 + 3], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, df[u * 4 + 0], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, df[u * 4 + 1], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, df[u * 4 + 2], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, df[u * 4 + 3], dp, 0, 0, 0);
+        }
+        // lane = q (col), reg r = key row crow(r,h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int key = k0 + crow(r, h2);
+            float ds = 0.f;
+            if (q_ok && key < len) {
+                float p = __expf(s[r] * scale - my_lse);
+                ds = p * (dp[r] - my_del) * scale;
+            }
+            s[r] = ds;
+        }
+        // dQ[q][d] += dS K   (A = regs: lane row = q, k-slot = key)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int kr = crow(r, h2);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                int col = nb * 32 + fl;
+                float kb = *reinterpret_cast<const float*>(sK + swz(kr, col >> 2) + (col & 3) * 4);
+                dq[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[r], kb, dq[nb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int q = q0 + w * 32 + crow(r, h2);
+        if (q < S) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) Elem<T>::st(dQ + (size_t)q * ld + nb * 32 + fl, dq[nb][r]);
+        }
+    }
+}
+
+extern "C" int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv,
+                            const int32_t* lens, int B, int S, int H, int dk, float scale, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(qkv && ctx && dctx && lse && delta && dqkv, "attn_bwd: null pointer");
+    FS2_CHECK_ARG(dk == DK, "attn_bwd: only d_k = 128 is supported (got %d)", dk);
+    if (B == 0) return FS2_OK;
+    long ld = 3L * H * DK, ldo = (long)H * DK;
+    int rows = B * S;
+    dim3 grid(fs2_cdiv(S, 128), H, B);
+    const int dyn = 163840;
+    if (dtype == FS2_F32) {
+        attn_delta_kernel<float><<<fs2_cdiv(rows * H, 4), 256, 0, stream>>>((const float*)ctx, (const float*)dctx, delta, rows, S, H);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
+        attn_bwd_dkv_kernel<float><<<grid, 256, dyn, stream>>>((const float*)qkv, ld, (const float*)dctx, ldo, lse, delta, (float*)dqkv, lens, S, H, scale);
+        attn_bwd_dq_kernel<float><<<grid, 256, 0, stream>>>((const float*)qkv, ld, (const float*)dctx, ldo, lse, delta, (float*)dqkv, lens, S, H, scale);
+    } else if (dtype == FS2_BF16) {
+        attn_delta_kernel<bf16_t><<<fs2_cdiv(rows * H, 4), 256, 0, stream>>>((const bf16_t*)ctx, (const bf16_t*)dctx, delta, rows, S, H);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
+        attn_bwd_dkv_kernel<bf16_t><<<grid, 256, dyn, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
+        attn_bwd_dq_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
+    } else { fs2_set_error("attn_bwd: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_LAUNCH("attn_bwd");
+    return FS2_OK;
+}

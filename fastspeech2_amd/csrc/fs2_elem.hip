@@ -1,0 +1,438 @@
+// fs2_elem.hip — HBM-bound gather / scatter / index kernels of the FastSpeech2 hot path.
+//   embedding + sinusoid PE        (reference transformer/Models.py:89-91)
+//   bucketize + embedding add      (reference model/modules.py:80-100,121,126)
+//   LengthRegulator index/gather   (reference model/modules.py:167-194, utils/tools.py:299-317)
+//   variance-predictor head 256->1 (reference model/modules.py:243-249)
+// Layout: activations are time-major rows [B*S][C], C contiguous. Index math is integer and bit-exact.
+#include "fs2_common.h"
+
+#define DISPATCH_DTYPE(dtype, ...)                                   \
+    if ((dtype) == FS2_F32) { typedef float T; __VA_ARGS__; }        \
+    else if ((dtype) == FS2_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+    else { fs2_set_error("unsupported dtype %d", (int)(dtype)); return FS2_EDTYPE; }
+
+// ------------------------------------------------------------------ embedding + PE
+// one 64-lane wave per row, float4 per lane-iteration.
+template <typename T>
+__global__ void embed_pe_kernel(const int64_t* __restrict__ tok, const float* __restrict__ emb,
+                                const float* __restrict__ pe, T* __restrict__ out, int rows, int L, int C, int V) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    int64_t id = tok[row];
+    if (id < 0 || id >= V) id = 0;
+    int t = row % L;
+    const float* e = emb + (size_t)id * C;
+    const float* p = pe + (size_t)t * C;
+    T* o = out + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 a = *reinterpret_cast<const float4*>(e + c);
+        float4 b = *reinterpret_cast<const float4*>(p + c);
+        st4<T>(o + c, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    }
+}
+
+extern "C" int fs2_embed_pe_fwd(const int64_t* tokens, const float* emb, const float* pe, void* out, int B, int L,
+                                int C, int V, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(tokens && emb && pe && out, "embed_pe_fwd: null pointer");
+    FS2_CHECK_ARG(B >= 0 && L > 0 && C > 0 && (C % 4) == 0, "embed_pe_fwd: bad shape B=%d L=%d C=%d", B, L, C);
+    int rows = B * L;
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, embed_pe_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>(tokens, emb, pe, (T*)out, rows, L, C, V));
+    FS2_CHECK_LAUNCH("embed_pe_fwd");
+    return FS2_OK;
+}
+
+// dEmb[tok[row]] += dY[row]; row pad_idx gets no gradient (padding_idx semantics).
+template <typename T>
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ tok, const T* __restrict__ dy, float* __restrict__ demb,
+                                 int rows, int C, int V, int pad_idx) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    int64_t id = tok[row];
+    if (id < 0 || id >= V || id == pad_idx) return;
+    float* g = demb + (size_t)id * C;
+    const T* d = dy + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = ld4<T>(d + c);
+        atomicAdd(g + c, v.x); atomicAdd(g + c + 1, v.y); atomicAdd(g + c + 2, v.z); atomicAdd(g + c + 3, v.w);
+    }
+}
+
+extern "C" int fs2_embed_bwd(const int64_t* tokens, const void* dy, float* demb, int rows, int C, int V, int pad_idx,
+                             int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(tokens && dy && demb, "embed_bwd: null pointer");
+    FS2_CHECK_ARG(rows >= 0 && C > 0 && (C % 4) == 0, "embed_bwd: bad shape");
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, embed_bwd_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>(tokens, (const T*)dy, demb, rows, C, V, pad_idx));
+    FS2_CHECK_LAUNCH("embed_bwd");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ x[b,t,:] += table[idx[b],:]  (speaker embedding)
+template <typename T>
+__global__ void add_rowvec_kernel(T* __restrict__ x, const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                  int rows, int S, int C, int V) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    int64_t id = idx[row / S];
+    if (id < 0 || id >= V) id = 0;
+    const float* e = table + (size_t)id * C;
+    T* o = x + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 a = ld4<T>(o + c);
+        float4 b = *reinterpret_cast<const float4*>(e + c);
+        st4<T>(o + c, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    }
+}
+extern "C" int fs2_add_rowvec(void* x, const float* table, const int64_t* idx, int B, int S, int C, int V, int dtype,
+                              hipStream_t stream) {
+    FS2_CHECK_ARG(x && table && idx, "add_rowvec: null pointer");
+    FS2_CHECK_ARG((C % 4) == 0, "add_rowvec: C%%4");
+    int rows = B * S;
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, add_rowvec_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>((T*)x, table, idx, rows, S, C, V));
+    FS2_CHECK_LAUNCH("add_rowvec");
+    return FS2_OK;
+}
+// d table[idx[b]] += sum_t dY[b,t,:]
+template <typename T>
+__global__ void rowvec_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dtable, const int64_t* __restrict__ idx,
+                                  int S, int C, int V) {
+    int b = blockIdx.x;
+    int64_t id = idx[b];
+    if (id < 0 || id >= V) id = 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += Elem<T>::ld(dy + ((size_t)b * S + t) * C + c);
+        atomicAdd(dtable + (size_t)id * C + c, s);
+    }
+}
+extern "C" int fs2_rowvec_bwd(const void* dy, float* dtable, const int64_t* idx, int B, int S, int C, int V, int dtype,
+                              hipStream_t stream) {
+    FS2_CHECK_ARG(dy && dtable && idx, "rowvec_bwd: null pointer");
+    if (B == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, rowvec_bwd_kernel<T><<<B, 256, 0, stream>>>((const T*)dy, dtable, idx, S, C, V));
+    FS2_CHECK_LAUNCH("rowvec_bwd");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ bucketize (right=False) + embedding add
+// idx = #{bins[i] < v}  == first i with bins[i] >= v   (torch.bucketize default; reference probe P3).
+__device__ __forceinline__ int bucketize_lb(const float* __restrict__ bins, int nb, float v) {
+    int lo = 0, hi = nb;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (bins[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <typename T>
+__global__ void bucket_embed_add_kernel(const T* __restrict__ x, const float* __restrict__ vals, float scale,
+                                        const float* __restrict__ bins, int nb, const float* __restrict__ emb,
+                                        T* __restrict__ out, int32_t* __restrict__ idx_out, int rows, int C) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    int id = bucketize_lb(bins, nb, vals[row] * scale);
+    if (lane == 0 && idx_out) idx_out[row] = id;
+    const float* e = emb + (size_t)id * C;
+    const T* xi = x + (size_t)row * C;
+    T* o = out + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 a = ld4<T>(xi + c);
+        float4 b = *reinterpret_cast<const float4*>(e + c);
+        st4<T>(o + c, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    }
+}
+extern "C" int fs2_bucket_embed_add_fwd(const void* x, const float* vals, float scale, const float* bins, int nbins,
+                                        const float* emb, void* out, int32_t* idx_out, int rows, int C, int dtype,
+                                        hipStream_t stream) {
+    FS2_CHECK_ARG(x && vals && bins && emb && out, "bucket_embed_add_fwd: null pointer");
+    FS2_CHECK_ARG((C % 4) == 0 && nbins >= 0, "bucket_embed_add_fwd: bad shape");
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, bucket_embed_add_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>(
+                              (const T*)x, vals, scale, bins, nbins, emb, (T*)out, idx_out, rows, C));
+    FS2_CHECK_LAUNCH("bucket_embed_add_fwd");
+    return FS2_OK;
+}
+template <typename T>
+__global__ void bucket_embed_bwd_kernel(const int32_t* __restrict__ idx, const T* __restrict__ dy, float* __restrict__ demb,
+                                        int rows, int C) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    float* g = demb + (size_t)idx[row] * C;
+    const T* d = dy + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = ld4<T>(d + c);
+        atomicAdd(g + c, v.x); atomicAdd(g + c + 1, v.y); atomicAdd(g + c + 2, v.z); atomicAdd(g + c + 3, v.w);
+    }
+}
+extern "C" int fs2_bucket_embed_bwd(const int32_t* idx, const void* dy, float* demb, int rows, int C, int dtype,
+                                    hipStream_t stream) {
+    FS2_CHECK_ARG(idx && dy && demb, "bucket_embed_bwd: null pointer");
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, bucket_embed_bwd_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>(idx, (const T*)dy, demb, rows, C));
+    FS2_CHECK_LAUNCH("bucket_embed_bwd");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ LengthRegulator
+// Step 1: per batch row, expand sizes n_i = max((int)d_i, 0) (truncation toward zero, reference
+// modules.py:186-187), exclusive prefix sum -> cum[b][i] (int32, L+1 entries), mel_len[b] = cum[b][L]
+// (NOT clipped to max_len: Appendix A #4), and the frame->phoneme map idx[b][t] (t < max_len),
+// -1 for padded frames.  One block per batch row; scan in LDS; binary search per frame.
+template <typename D>
+__global__ void lr_index_kernel(const D* __restrict__ dur, int L, int T, int32_t* __restrict__ cum,
+                                int32_t* __restrict__ idx, int64_t* __restrict__ mel_len) {
+    extern __shared__ int32_t s_cum[];  // L+1
+    __shared__ int32_t s_part[256];
+    int b = blockIdx.x;
+    const D* d = dur + (size_t)b * L;
+    // chunked scan: each thread owns a contiguous chunk
+    int per = (L + blockDim.x - 1) / blockDim.x;
+    int lo = threadIdx.x * per, hi = min(lo + per, L);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) {
+        int n = (int)d[i];
+        s += n > 0 ? n : 0;
+    }
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < (int)blockDim.x; ++i) { int v = s_part[i]; s_part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = s_part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) {
+        s_cum[i] = run;
+        int n = (int)d[i];
+        run += n > 0 ? n : 0;
+    }
+    if (hi == L && lo < L) s_cum[L] = run;
+    if (L == 0 && threadIdx.x == 0) s_cum[0] = 0;
+    __syncthreads();
+    int total = s_cum[L];
+    for (int i = threadIdx.x; i <= L; i += blockDim.x) cum[(size_t)b * (L + 1) + i] = s_cum[i];
+    if (threadIdx.x == 0) mel_len[b] = (int64_t)total;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        int r = -1;
+        if (t < total) {
+            // largest i with cum[i] <= t  (segments with n_i = 0 are skipped automatically)
+            int a = 0, c = L;  // invariant: cum[a] <= t < cum[c]
+            while (c - a > 1) {
+                int m = (a + c) >> 1;
+                if (s_cum[m] <= t) a = m; else c = m;
+            }
+            r = a;
+        }
+        idx[(size_t)b * T + t] = r;
+    }
+}
+
+extern "C" int fs2_lr_index(const void* durations, int dur_is_float, int B, int L, int T, int32_t* cum, int32_t* idx,
+                            int64_t* mel_len, hipStream_t stream) {
+    FS2_CHECK_ARG(durations && cum && idx && mel_len, "lr_index: null pointer");
+    FS2_CHECK_ARG(B >= 0 && L >= 0 && T >= 0, "lr_index: bad shape");
+    FS2_CHECK_ARG((size_t)(L + 1) * 4 <= 60000, "lr_index: L=%d too large for LDS scan", L);
+    if (B == 0) return FS2_OK;
+    size_t sh = (size_t)(L + 1) * sizeof(int32_t);
+    if (dur_is_float)
+        lr_index_kernel<float><<<B, 256, sh, stream>>>((const float*)durations, L, T, cum, idx, mel_len);
+    else
+        lr_index_kernel<int64_t><<<B, 256, sh, stream>>>((const int64_t*)durations, L, T, cum, idx, mel_len);
+    FS2_CHECK_LAUNCH("lr_index");
+    return FS2_OK;
+}
+
+// Step 2: out[b,t,:] = (idx>=0 ? x[b,idx,:] : 0) + (pe ? pe[t,:] : 0).  One wave per output row.
+template <typename T>
+__global__ void lr_gather_kernel(const T* __restrict__ x, const int32_t* __restrict__ idx, const float* __restrict__ pe,
+                                 T* __restrict__ out, int rows, int L, int Tm, int C) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    int b = row / Tm, t = row - b * Tm;
+    int i = idx[row];
+    const T* src = x + ((size_t)b * L + (i < 0 ? 0 : i)) * C;
+    T* o = out + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= 0) v = ld4<T>(src + c);
+        if (pe) {
+            float4 p = *reinterpret_cast<const float4*>(pe + (size_t)t * C + c);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        st4<T>(o + c, v);
+    }
+}
+extern "C" int fs2_lr_gather_fwd(const void* x, const int32_t* idx, const float* pe, void* out, int B, int L, int Tm,
+                                 int C, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && idx && out, "lr_gather_fwd: null pointer");
+    FS2_CHECK_ARG((C % 4) == 0, "lr_gather_fwd: C%%4");
+    int rows = B * Tm;
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, lr_gather_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>((const T*)x, idx, pe, (T*)out, rows, L, Tm, C));
+    FS2_CHECK_LAUNCH("lr_gather_fwd");
+    return FS2_OK;
+}
+// Backward: segment sum. dX[b,i,:] (+)= sum_{t=cum[i]}^{min(cum[i+1],T)-1} dY[b,t,:]; contiguous, no atomics.
+template <typename T>
+__global__ void lr_gather_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ cum, T* __restrict__ dx,
+                                     int rows, int L, int Tm, int C, int accumulate) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // row = b*L + i
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    int b = row / L, i = row - b * L;
+    int t0 = cum[(size_t)b * (L + 1) + i], t1 = cum[(size_t)b * (L + 1) + i + 1];
+    t0 = min(t0, Tm); t1 = min(t1, Tm);
+    T* o = dx + (size_t)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accumulate) s = ld4<T>(o + c);
+        for (int t = t0; t < t1; ++t) {
+            float4 v = ld4<T>(dy + ((size_t)b * Tm + t) * C + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        st4<T>(o + c, s);
+    }
+}
+extern "C" int fs2_lr_gather_bwd(const void* dy, const int32_t* cum, void* dx, int B, int L, int Tm, int C, int accumulate,
+                                 int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(dy && cum && dx, "lr_gather_bwd: null pointer");
+    FS2_CHECK_ARG((C % 4) == 0, "lr_gather_bwd: C%%4");
+    int rows = B * L;
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, lr_gather_bwd_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>((const T*)dy, cum, (T*)dx, rows, L, Tm, C, accumulate));
+    FS2_CHECK_LAUNCH("lr_gather_bwd");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ inference durations
+// d_rounded = clamp(round_half_even(exp(log_d) - 1) * d_control, min=0)   (reference modules.py:132-135)
+__global__ void duration_round_kernel(const float* __restrict__ logd, float d_control, float* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = rintf(expf(logd[i]) - 1.0f) * d_control;
+    out[i] = fmaxf(v, 0.0f);
+}
+extern "C" int fs2_duration_round(const float* logd, float d_control, float* out, int n, hipStream_t stream) {
+    FS2_CHECK_ARG(logd && out, "duration_round: null pointer");
+    if (n == 0) return FS2_OK;
+    duration_round_kernel<<<fs2_cdiv(n, 256), 256, 0, stream>>>(logd, d_control, out, n);
+    FS2_CHECK_LAUNCH("duration_round");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ predictor head: out[r] = masked(dot(x[r],w)+b)
+template <typename T>
+__global__ void rowdot_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  const int32_t* __restrict__ lens, float* __restrict__ out, int rows, int S, int C) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    const T* xi = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 a = ld4<T>(xi + c);
+        float4 b = *reinterpret_cast<const float4*>(w + c);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        int b = row / S, t = row - b * S;
+        bool pad = lens && t >= lens[b];
+        out[row] = pad ? 0.0f : s + bias[0];
+    }
+}
+extern "C" int fs2_rowdot_fwd(const void* x, const float* w, const float* bias, const int32_t* lens, float* out, int B,
+                              int S, int C, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && w && bias && out, "rowdot_fwd: null pointer");
+    FS2_CHECK_ARG((C % 4) == 0, "rowdot_fwd: C%%4");
+    int rows = B * S;
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, rowdot_fwd_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>((const T*)x, w, bias, lens, out, rows, S, C));
+    FS2_CHECK_LAUNCH("rowdot_fwd");
+    return FS2_OK;
+}
+// backward: dx[r,:] = g[r]*w (g masked), dw += sum_r g[r]*x[r,:], db += sum_r g[r].
+// grid-stride over rows per block; block-level accumulation of dw in registers, one atomic per block per channel.
+template <typename T>
+__global__ void rowdot_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
+                                  const int32_t* __restrict__ lens, T* __restrict__ dx, float* __restrict__ dw,
+                                  float* __restrict__ db, int rows, int S, int C) {
+    // thread c-slot owns channels c, c+blockDim, ... ; rows strided by gridDim
+    __shared__ float s_db[256];
+    float gsum = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float wc = w[c], acc = 0.f;
+        for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+            int b = row / S, t = row - b * S;
+            float gr = (lens && t >= lens[b]) ? 0.f : g[row];
+            acc += gr * Elem<T>::ld(x + (size_t)row * C + c);
+            Elem<T>::st(dx + (size_t)row * C + c, gr * wc);
+            if (c == (int)threadIdx.x && threadIdx.x == 0) gsum += gr;
+        }
+        atomicAdd(dw + c, acc);
+    }
+    if (threadIdx.x == 0) atomicAdd(db, gsum);
+    (void)s_db;
+}
+extern "C" int fs2_rowdot_bwd(const void* x, const float* w, const float* g, const int32_t* lens, void* dx, float* dw,
+                              float* db, int B, int S, int C, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && w && g && dx && dw && db, "rowdot_bwd: null pointer");
+    int rows = B * S;
+    if (rows == 0) return FS2_OK;
+    int grid = rows < 512 ? rows : 512;
+    DISPATCH_DTYPE(dtype, rowdot_bwd_kernel<T><<<grid, 256, 0, stream>>>((const T*)x, w, g, lens, (T*)dx, dw, db, rows, S, C));
+    FS2_CHECK_LAUNCH("rowdot_bwd");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ zero padded rows in place (masked_fill(mask,0))
+template <typename T>
+__global__ void mask_rows_kernel(T* __restrict__ x, const int32_t* __restrict__ lens, int rows, int S, int C) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int b = row / S, t = row - b * S;
+    if (t < lens[b]) return;
+    int lane = threadIdx.x & 63;
+    for (int c = lane * 4; c < C; c += 256) st4<T>(x + (size_t)row * C + c, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+extern "C" int fs2_mask_rows(void* x, const int32_t* lens, int B, int S, int C, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && lens, "mask_rows: null pointer");
+    FS2_CHECK_ARG((C % 4) == 0, "mask_rows: C%%4");
+    int rows = B * S;
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, mask_rows_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>((T*)x, lens, rows, S, C));
+    FS2_CHECK_LAUNCH("mask_rows");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ dtype casts (fp32 <-> bf16) & axpy helpers
+__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n4; i += (size_t)gridDim.x * blockDim.x) st4<bf16_t>(out + i * 4, *reinterpret_cast<const float4*>(in + i * 4));
+}
+__global__ void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n4; i += (size_t)gridDim.x * blockDim.x) *reinterpret_cast<float4*>(out + i * 4) = ld4<bf16_t>(in + i * 4);
+}
+extern "C" int fs2_cast(const void* in, int in_dtype, void* out, int out_dtype, size_t n, hipStream_t stream) {
+    FS2_CHECK_ARG(in && out, "cast: null pointer");
+    FS2_CHECK_ARG((n % 4) == 0, "cast: n%%4");
+    if (n == 0) return FS2_OK;
+    size_t n4 = n / 4;
+    int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    if (in_dtype == FS2_F32 && out_dtype == FS2_BF16)
+        cast_f32_to_bf16_kernel<<<grid, 256, 0, stream>>>((const float*)in, (bf16_t*)out, n4);
+    else if (in_dtype == FS2_BF16 && out_dtype == FS2_F32)
+        cast_bf16_to_f32_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)in, (float*)out, n4);
+    else { fs2_set_error("cast: unsupported dtype pair %d->%d", in_dtype, out_dtype); return FS2_EDTYPE; }
+    FS2_CHECK_LAUNCH("cast");
+    return FS2_OK;
+}

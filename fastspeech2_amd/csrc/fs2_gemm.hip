@@ -1,0 +1,444 @@
+// fs2_gemm.hip — the MFMA contraction core of the hot path (gfx950).
+//
+// ONE implicit-GEMM kernel family covers every dense contraction of FastSpeech2 / HiFi-GAN / STFT:
+//   Linear (taps=1), Conv1d k=3/5/7/9/11 with dilation (taps=k), their data gradients (same kernel,
+//   tap-flipped packed weights), ConvTranspose1d (polyphase -> 3-tap conv with N = stride*Cout) and the
+//   framed DFT (ldx = hop).  Reference call sites: transformer/SubLayers.py:39-41,54,87-88;
+//   model/modules.py:209-240; model/fastspeech2.py:95; transformer/Layers.py:129-137;
+//   hifigan/models.py:96-165; audio/stft.py:60-72.
+//
+// Layout: activations are time-major rows X[M][Cin] (M = B*S, row m = b*S + t), so a conv tap is a ROW
+// shift and no transpose(1,2).contiguous() ever runs.  Weights are pre-packed K-contiguous W[N][taps][Cin]
+// in the compute dtype ("NT" GEMM: both operands K-contiguous, identical staging for A and B).
+//
+// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 blocks);
+// K-tile = 128 bytes per row (32 f32 / 64 bf16).  LDS rows are 128 B, 16-B chunks XOR-swizzled with
+// ((row>>1)&7) so both the ds_write_b128 staging and the ds_read_b128 fragment reads are conflict-free
+// (guide §5.5 T2).  f32 path: v_mfma_f32_32x32x2_f32 (exact f32, 157 TF roof); bf16 path:
+// v_mfma_f32_32x32x16_bf16 (2.5 PF roof), fp32 accumulate in both.
+// Register-staged double buffering: global loads of K-tile t+1 are issued before the MFMAs of tile t and
+// written to the other LDS buffer afterwards (one barrier per K-tile).
+#include "fs2_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvGemmArgs {
+    const void* X; long ldx;
+    const void* W; long ldw;       // packed [N][taps*Cin]
+    const float* bias;             // [N] or null
+    const void* R; long ldr;       // residual added after activation, or null
+    void* Y; long ldy;
+    const int32_t* lens;           // per-sequence valid rows (rows t >= lens[b] are written as 0) or null
+    int M, N, Cin, S, taps, dil, pad;
+    int act; float slope;          // output activation
+    int in_act; float in_slope;    // activation applied to X on load (leaky-relu prologue of HiFi-GAN)
+    int accumulate; float out_scale;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case FS2_ACT_RELU: return fmaxf(v, 0.f);
+        case FS2_ACT_TANH: return tanhf(v);
+        case FS2_ACT_LRELU: return v > 0.f ? v : v * slope;
+        default: return v;
+    }
+}
+
+template <typename T> struct MmaTraits;
+template <> struct MmaTraits<float> { static constexpr int EPC = 4; };   // elements per 16-B chunk
+template <> struct MmaTraits<bf16_t> { static constexpr int EPC = 8; };
+
+__device__ __forceinline__ uint4 act_chunk_f32(uint4 v, float slope) {
+    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = f[i] > 0.f ? f[i] : f[i] * slope;
+    return v;
+}
+__device__ __forceinline__ uint4 act_chunk_bf16(uint4 v, float slope) {
+    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+        lo = lo > 0.f ? lo : lo * slope;
+        hi = hi > 0.f ? hi : hi * slope;
+        u[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    }
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
+    constexpr int EPC = MmaTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * 128];  // [buf][A|B][128 rows][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (a.N + 127) >> 7;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* W = reinterpret_cast<const T*>(a.W);
+    T* Y = reinterpret_cast<T*>(a.Y);
+    const T* R = reinterpret_cast<const T*>(a.R);
+
+    // fully padded M-tile inside one sequence: write zeros and leave.
+    if (a.lens) {
+        int mlast = min(m0 + 127, a.M - 1);
+        int b0 = m0 / a.S, b1 = mlast / a.S;
+        if (b0 == b1 && (m0 - b0 * a.S) >= a.lens[b0]) {
+            if (!a.accumulate) {
+                for (int i = tid; i < 128 * 128; i += 256) {
+                    int r = i >> 7, c = i & 127;
+                    int m = m0 + r, n = n0 + c;
+                    if (m < a.M && n < a.N) Elem<T>::st(Y + (size_t)m * a.ldy + n, 0.f);
+                }
+            }
+            return;
+        }
+    }
+
+    // staging assignment: thread -> 16-B chunk c of rows r_i = (tid>>3) + 32 i
+    const int sc = tid & 7, sr = tid >> 3;
+    int a_t[4];   // time index of the A row within its sequence, or a large negative if m >= M
+    size_t a_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + sr + 32 * i;
+        a_t[i] = (m < a.M) ? (m % a.S) : -(1 << 28);
+        a_off[i] = (size_t)m * a.ldx;
+    }
+    const int nkc = (a.Cin + BK - 1) / BK;
+    const int nk = a.taps * nkc;
+
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+        int tap = kt / nkc, kc = kt - tap * nkc;
+        int shift = tap * a.dil - a.pad;
+        int col = kc * BK + sc * EPC;
+        bool colok = col < a.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ts = a_t[i] + shift;
+            bool ok = colok && ts >= 0 && ts < a.S;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *reinterpret_cast<const uint4*>(X + (a_off[i] + (long)shift * a.ldx + col));
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int n = n0 + sr + 32 * i;
+            bool ok = colok && n < a.N;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *reinterpret_cast<const uint4*>(W + ((size_t)n * a.ldw + (size_t)tap * a.Cin + col));
+            rb[i] = v;
+        }
+        if (a.in_act == FS2_ACT_LRELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = (sizeof(T) == 4) ? act_chunk_f32(ra[i], a.in_slope) : act_chunk_bf16(ra[i], a.in_slope);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* As = smem + buf * 32768;
+        unsigned char* Bs = As + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = sr + 32 * i;
+            int off = r * 128 + ((sc ^ ((r >> 1) & 7)) << 4);
+            *reinterpret_cast<uint4*>(As + off) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + off) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fl = lane & 31, fh = lane >> 5;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* As = smem + (kt & 1) * 32768;
+        const unsigned char* Bs = As + 16384;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 af[2], bf[2];
+            int c = fh * 4 + j;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                int r = wm * 64 + mb * 32 + fl;
+                af[mb] = *reinterpret_cast<const uint4*>(As + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                int r = wn * 64 + nb * 32 + fl;
+                bf[nb] = *reinterpret_cast<const uint4*>(Bs + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                reinterpret_cast<const float*>(&af[mb])[jj], reinterpret_cast<const float*>(&bf[nb])[jj],
+                                acc[mb][nb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, af[mb]), __builtin_bit_cast(bf16x8, bf[nb]), acc[mb][nb], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: C layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int n = n0 + wn * 64 + nb * 32 + fl;
+        if (n >= a.N) continue;
+        float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= a.M) continue;
+                float v = apply_act(acc[mb][nb][r] + bv, a.act, a.slope);
+                if (R) v += Elem<T>::ld(R + (size_t)m * a.ldr + n);
+                v *= a.out_scale;
+                if (a.lens) {
+                    int b = m / a.S;
+                    if (m - b * a.S >= a.lens[b]) v = 0.f;
+                }
+                T* yp = Y + (size_t)m * a.ldy + n;
+                if (a.accumulate) v += Elem<T>::ld(yp);
+                Elem<T>::st(yp, v);
+            }
+        }
+    }
+}
+
+extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
+                             long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad,
+                             int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
+                             hipStream_t stream) {
+    FS2_CHECK_ARG(X && W && Y, "conv_gemm: null pointer");
+    FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0 && dil > 0, "conv_gemm: bad shape M=%d N=%d Cin=%d S=%d taps=%d", M, N, Cin, S, taps);
+    FS2_CHECK_ARG(M % S == 0, "conv_gemm: M=%d not a multiple of S=%d", M, S);
+    int epc = dtype == FS2_F32 ? 4 : 8;
+    FS2_CHECK_ARG(dtype == FS2_F32 || dtype == FS2_BF16, "conv_gemm: dtype %d", dtype);
+    FS2_CHECK_ARG(Cin % epc == 0 && ldx % epc == 0, "conv_gemm: Cin=%d / ldx=%ld must be multiples of %d", Cin, ldx, epc);
+    FS2_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0, "conv_gemm: X/W must be 16-byte aligned");
+    if (M == 0) return FS2_OK;
+    ConvGemmArgs a;
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = (long)taps * Cin; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
+    a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps; a.dil = dil; a.pad = pad; a.act = act;
+    a.slope = slope; a.in_act = in_act; a.in_slope = in_slope; a.accumulate = accumulate; a.out_scale = out_scale;
+    long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
+    if (dtype == FS2_F32) conv_gemm_kernel<float><<<(unsigned)grid, 256, 0, stream>>>(a);
+    else conv_gemm_kernel<bf16_t><<<(unsigned)grid, 256, 0, stream>>>(a);
+    FS2_CHECK_LAUNCH("conv_gemm");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ weight packing
+// torch Conv1d weight (Cout, Cin, k) fp32 -> forward pack  Wf[n][j][c]       = W[n][c][j]
+//                                          -> dgrad pack    Wd[c][j][n]       = W[n][c][k-1-j]
+// Linear weight (N, K) is the k=1 case.  Output in the compute dtype.
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin, int k) {
+    size_t total = (size_t)Cout * Cin * k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // i indexes the forward pack (coalesced writes): i = (n*k + j)*Cin + c
+        int c = (int)(i % Cin);
+        size_t q = i / Cin;
+        int j = (int)(q % k);
+        int n = (int)(q / k);
+        float v = w[((size_t)n * Cin + c) * k + j];
+        if (wf) Elem<T>::st(wf + i, v);
+        if (wd) Elem<T>::st(wd + ((size_t)c * k + (k - 1 - j)) * Cout + n, v);
+    }
+}
+extern "C" int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(w && (wf || wd), "pack_weight: null pointer");
+    size_t total = (size_t)Cout * Cin * k;
+    if (total == 0) return FS2_OK;
+    int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == FS2_F32) pack_weight_kernel<float><<<grid, 256, 0, stream>>>(w, (float*)wf, (float*)wd, Cout, Cin, k);
+    else if (dtype == FS2_BF16) pack_weight_kernel<bf16_t><<<grid, 256, 0, stream>>>(w, (bf16_t*)wf, (bf16_t*)wd, Cout, Cin, k);
+    else { fs2_set_error("pack_weight: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_LAUNCH("pack_weight");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ weight gradient (TN contraction over rows)
+// dW[n][c][j] (torch layout (Cout,Cin,k), fp32, atomically accumulated) = sum_m dY[m][n] * X[m + j*dil - pad][c]
+// Block: 128 (n) x 128 (c) output tile for one tap, split-K over row ranges; K-tile = 32 rows.
+// f32: LDS tiles [32 rows][128] f32, fragments by ds_read_b32 (lanes along n / c: conflict-free),
+//      v_mfma_f32_32x32x2_f32.
+// bf16 inputs are widened to f32 when staged (first version; a bf16-MFMA wgrad with transposing
+// LDS reads replaces this in a later revision).
+struct WgradArgs {
+    const void* dY; long lddy;
+    const void* X; long ldx;
+    float* dW;
+    int M, N, Cin, S, taps, dil, pad, rows_per_split;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[2][32][128];  // dY tile  [row][n]
+    __shared__ __attribute__((aligned(16))) float sB[2][32][128];  // X tile   [row][c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
+    int bx = blockIdx.x;
+    const int tile_n = bx % ntn; bx /= ntn;
+    const int tile_c = bx % ntc; bx /= ntc;
+    const int tap = bx;
+    const int n0 = tile_n * 128, c0 = tile_c * 128;
+    const int shift = tap * a.dil - a.pad;
+    const int mbeg = blockIdx.y * a.rows_per_split;
+    const int mend = min(a.M, mbeg + a.rows_per_split);
+    if (mbeg >= mend) return;
+    const T* dY = reinterpret_cast<const T*>(a.dY);
+    const T* X = reinterpret_cast<const T*>(a.X);
+
+    // staging: tile 32 rows x 128 cols = 1024 float4 -> 4 per thread: row = (tid>>5) + 8 i, col4 = tid&31
+    const int sr = tid >> 5, sc4 = (tid & 31) * 4;
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = mt + sr + 8 * i;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (m < mend) {
+                int n = n0 + sc4;
+                if (n < a.N) va = ld4<T>(dY + (size_t)m * a.lddy + n);
+                int t = m % a.S, ts = t + shift;
+                int c = c0 + sc4;
+                if (ts >= 0 && ts < a.S && c < a.Cin) vb = ld4<T>(X + (size_t)(m + shift) * a.ldx + c);
+            }
+            ra[i] = va; rb[i] = vb;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&sA[buf][sr + 8 * i][sc4]) = ra[i];
+            *reinterpret_cast<float4*>(&sB[buf][sr + 8 * i][sc4]) = rb[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fl = lane & 31, fh = lane >> 5;
+    int nt = (mend - mbeg + 31) / 32;
+    load_tile(mbeg);
+    store_tile(0);
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        if (it + 1 < nt) load_tile(mbeg + (it + 1) * 32);
+        int buf = it & 1;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float af[2], bf[2];
+            int row = ks * 2 + fh;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb] = sA[buf][row][wm * 64 + mb * 32 + fl];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) bf[nb] = sB[buf][row][wn * 64 + nb * 32 + fl];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mb], bf[nb], acc[mb][nb], 0, 0, 0);
+        }
+        if (it + 1 < nt) store_tile((it + 1) & 1);
+        __syncthreads();
+    }
+    // acc[mb][nb][r]: row (n index) = wm*64+mb*32+(r&3)+8*(r>>2)+4*fh ; col (c index) = wn*64+nb*32+fl
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int c = c0 + wn * 64 + nb * 32 + fl;
+        if (c >= a.Cin) continue;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n = n0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n >= a.N) continue;
+                atomicAdd(a.dW + ((size_t)n * a.Cin + c) * a.taps + tap, acc[mb][nb][r]);
+            }
+    }
+}
+
+extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int S,
+                              int taps, int dil, int pad, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(dY && X && dW, "conv_wgrad: null pointer");
+    FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0, "conv_wgrad: bad shape");
+    FS2_CHECK_ARG(N % 4 == 0 && Cin % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0, "conv_wgrad: N/Cin/ld must be multiples of 4");
+    if (M == 0) return FS2_OK;
+    WgradArgs a;
+    a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps;
+    a.dil = dil; a.pad = pad;
+    long tiles = (long)fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128) * taps;
+    // split rows so that ~1024 workgroups exist, each covering a multiple of 32 rows (>= 256 rows).
+    long want = (1024 + tiles - 1) / tiles;
+    long rps = (M + want - 1) / want;
+    rps = ((rps + 31) / 32) * 32;
+    if (rps < 256) rps = 256;
+    a.rows_per_split = (int)rps;
+    int splits = fs2_cdiv(M, rps);
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
+    else if (dtype == FS2_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
+    else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_LAUNCH("conv_wgrad");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+// out[n] += sum_m x[m][n].  grid (ceil(N/64), row-splits); each wave owns 64 columns (coalesced 256-B rows for f32).
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, int M, int N, int rows_per_block) {
+    __shared__ float s[4][64];
+    int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    int w = threadIdx.x >> 6;
+    int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
+    float acc = 0.f;
+    if (col < N)
+        for (int m = mbeg + w; m < mend; m += 4) acc += Elem<T>::ld(x + (size_t)m * ldx + col);
+    s[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && col < N) atomicAdd(out + col, s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+extern "C" int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && out, "colsum: null pointer");
+    if (M == 0 || N == 0) return FS2_OK;
+    int rpb = 256;
+    dim3 grid(fs2_cdiv(N, 64), fs2_cdiv(M, rpb));
+    if (dtype == FS2_F32) colsum_kernel<float><<<grid, 256, 0, stream>>>((const float*)x, ldx, out, M, N, rpb);
+    else if (dtype == FS2_BF16) colsum_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)x, ldx, out, M, N, rpb);
+    else { fs2_set_error("colsum: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_LAUNCH("colsum");
+    return FS2_OK;
+}

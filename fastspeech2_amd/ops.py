@@ -1,0 +1,253 @@
+"""Tensor-level wrappers over the C ABI (include/fs2hip.h).
+
+PyTorch is used only as plumbing: device memory (torch.empty), the current HIP stream and dtype bookkeeping.
+Every function launches hand-written HIP kernels through ctypes; nothing here computes with torch ops.
+"""
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
+
+
+def dt(t_or_dtype):
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return F32
+    if d == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {d}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "fs2 ops need device tensors (no CPU fallback)"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _contig(t):
+    assert t.is_contiguous(), "fs2 ops need contiguous tensors"
+    return t
+
+
+# ------------------------------------------------------------------ weights
+def pack_weight(w, dtype, want_fwd=True, want_dgrad=True, wf=None, wd=None):
+    """w: (Cout, Cin, k) or (N, K) fp32 -> (Wf [Cout][k][Cin], Wd [Cin][k][Cout]) in `dtype`."""
+    w = _contig(w)
+    if w.dim() == 2:
+        cout, cin, k = w.shape[0], w.shape[1], 1
+    else:
+        cout, cin, k = w.shape
+    if want_fwd and wf is None:
+        wf = torch.empty(cout, k, cin, device=w.device, dtype=dtype)
+    if want_dgrad and wd is None:
+        wd = torch.empty(cin, k, cout, device=w.device, dtype=dtype)
+    _lib.call("fs2_pack_weight", _p(w), _p(wf) if want_fwd else None, _p(wd) if want_dgrad else None, cout, cin, k,
+              dt(dtype), _stream())
+    return wf, wd
+
+
+# ------------------------------------------------------------------ contraction
+def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0, lens=None, res=None, out=None,
+              in_act=ACT_NONE, in_slope=0.0, accumulate=False, out_scale=1.0, ldx=None, M=None, Cin=None, N=None,
+              ldy=None):
+    """x: [M, Cin] rows (or any buffer with row stride ldx); wpacked: [N, taps, Cin]; returns [M, N]."""
+    if M is None:
+        M = x.shape[0]
+    if Cin is None:
+        Cin = wpacked.shape[-1]
+    if N is None:
+        N = wpacked.shape[0]
+    if ldx is None:
+        ldx = x.stride(0)
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=x.dtype)
+    if ldy is None:
+        ldy = out.stride(0) if out.dim() == 2 else N
+    ldr = res.stride(0) if res is not None else 0
+    _lib.call("fs2_conv_gemm", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), M, N, Cin, S,
+              taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
+    return out
+
+
+def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0):
+    """dw (Cout, Cin, k) fp32 += dy^T * shifted x."""
+    M, N = dy.shape
+    Cin = x.shape[1]
+    _lib.call("fs2_conv_wgrad", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), M, N, Cin, S, taps, dil, pad, dt(dy),
+              _stream())
+
+
+def colsum(x, out):
+    M, N = x.shape
+    _lib.call("fs2_colsum", _p(x), x.stride(0), _p(out), M, N, dt(x), _stream())
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(qkv, lens, B, S, H, dk=128):
+    ctx = torch.empty(B * S, H * dk, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, H, S, device=qkv.device, dtype=torch.float32)
+    _lib.call("fs2_attn_fwd", _p(qkv), _p(ctx), _p(lse), _p(lens), B, S, H, dk, float(dk) ** -0.5, dt(qkv), _stream())
+    return ctx, lse
+
+
+def attn_bwd(qkv, ctx, dctx, lse, lens, B, S, H, dk=128):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    _lib.call("fs2_attn_bwd", _p(qkv), _p(ctx), _p(dctx), _p(lse), _p(delta), _p(dqkv), _p(lens), B, S, H, dk,
+              float(dk) ** -0.5, dt(qkv), _stream())
+    return dqkv
+
+
+# ------------------------------------------------------------------ layer norm
+def ln_fwd(y, res, gamma, beta, lens, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0):
+    C = y.shape[-1]
+    out = torch.empty_like(y)
+    mean = torch.empty(B * S, device=y.device, dtype=torch.float32)
+    rstd = torch.empty(B * S, device=y.device, dtype=torch.float32)
+    _lib.call("fs2_ln_fwd", _p(y), _p(res), _p(gamma), _p(beta), _p(lens), _p(out), _p(mean), _p(rstd), B, S, C, eps,
+              p_pre, seed_pre, p_post, seed_post, dt(y), _stream())
+    return out, mean, rstd
+
+
+def ln_bwd(z, dout, gamma, lens, mean, rstd, dgamma, dbeta, B, S, want_d1=True, want_d2=False, d1_add=None, p_pre=0.0,
+           seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False):
+    C = z.shape[-1]
+    d1 = torch.empty_like(z) if want_d1 else None
+    d2 = torch.empty_like(z) if want_d2 else None
+    _lib.call("fs2_ln_bwd", _p(z), _p(dout), _p(gamma), _p(lens), _p(mean), _p(rstd), _p(d1_add), _p(d1), _p(d2),
+              _p(dgamma), _p(dbeta), B, S, C, p_pre, seed_pre, p_post, seed_post, int(relu_bwd), dt(z), _stream())
+    return d1, d2
+
+
+# ------------------------------------------------------------------ batch norm
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e-5, momentum=0.1):
+    M, C = x.shape
+    stats = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    mean_rstd = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    _lib.call("fs2_bn_stats", _p(x), _p(stats), M, C, dt(x), _stream())
+    _lib.call("fs2_bn_finalize", _p(stats), _p(running_mean), _p(running_var), _p(mean_rstd), M, C, eps, momentum,
+              _stream())
+    out = torch.empty_like(x)
+    _lib.call("fs2_bn_apply", _p(x), _p(mean_rstd), _p(gamma), _p(beta), _p(out), M, C, act, p, seed, dt(x), _stream())
+    return out, mean_rstd
+
+
+def bn_bwd(x, dout, mean_rstd, gamma, beta, act, p, seed):
+    M, C = x.shape
+    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    _lib.call("fs2_bn_bwd", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(sums), _p(dx), M, C, act, p, seed,
+              dt(x), _stream())
+    return dx, sums[C:], sums[:C]  # dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------ gathers
+def embed_pe_fwd(tokens, emb, pe, dtype):
+    B, L = tokens.shape
+    V, C = emb.shape
+    out = torch.empty(B * L, C, device=emb.device, dtype=dtype)
+    _lib.call("fs2_embed_pe_fwd", _p(tokens), _p(emb), _p(pe), _p(out), B, L, C, V, dt(dtype), _stream())
+    return out
+
+
+def embed_bwd(tokens, dy, demb, pad_idx=0):
+    V, C = demb.shape
+    _lib.call("fs2_embed_bwd", _p(tokens), _p(dy), _p(demb), tokens.numel(), C, V, pad_idx, dt(dy), _stream())
+
+
+def add_rowvec(x, table, idx, B, S):
+    V, C = table.shape
+    _lib.call("fs2_add_rowvec", _p(x), _p(table), _p(idx), B, S, C, V, dt(x), _stream())
+
+
+def rowvec_bwd(dy, dtable, idx, B, S):
+    V, C = dtable.shape
+    _lib.call("fs2_rowvec_bwd", _p(dy), _p(dtable), _p(idx), B, S, C, V, dt(dy), _stream())
+
+
+def bucket_embed_add_fwd(x, vals, scale, bins, emb):
+    rows, C = x.shape
+    out = torch.empty_like(x)
+    idx = torch.empty(rows, device=x.device, dtype=torch.int32)
+    _lib.call("fs2_bucket_embed_add_fwd", _p(x), _p(vals), float(scale), _p(bins), bins.numel(), _p(emb), _p(out),
+              _p(idx), rows, C, dt(x), _stream())
+    return out, idx
+
+
+def bucket_embed_bwd(idx, dy, demb):
+    rows, C = dy.shape
+    _lib.call("fs2_bucket_embed_bwd", _p(idx), _p(dy), _p(demb), rows, C, dt(dy), _stream())
+
+
+def lr_index(durations, T):
+    B, L = durations.shape
+    is_float = durations.dtype == torch.float32
+    assert is_float or durations.dtype == torch.int64
+    dev = durations.device
+    cum = torch.empty(B, L + 1, device=dev, dtype=torch.int32)
+    idx = torch.empty(B, T, device=dev, dtype=torch.int32)
+    mel_len = torch.empty(B, device=dev, dtype=torch.int64)
+    _lib.call("fs2_lr_index", _p(_contig(durations)), int(is_float), B, L, T, _p(cum), _p(idx), _p(mel_len), _stream())
+    return cum, idx, mel_len
+
+
+def lr_gather_fwd(x, idx, pe, B, L, T):
+    C = x.shape[-1]
+    out = torch.empty(B * T, C, device=x.device, dtype=x.dtype)
+    _lib.call("fs2_lr_gather_fwd", _p(x), _p(idx), _p(pe), _p(out), B, L, T, C, dt(x), _stream())
+    return out
+
+
+def lr_gather_bwd(dy, cum, B, L, T, dx=None, accumulate=False):
+    C = dy.shape[-1]
+    if dx is None:
+        dx = torch.empty(B * L, C, device=dy.device, dtype=dy.dtype)
+    _lib.call("fs2_lr_gather_bwd", _p(dy), _p(cum), _p(dx), B, L, T, C, int(accumulate), dt(dy), _stream())
+    return dx
+
+
+def duration_round(logd, d_control):
+    out = torch.empty_like(logd)
+    _lib.call("fs2_duration_round", _p(logd), float(d_control), _p(out), logd.numel(), _stream())
+    return out
+
+
+def rowdot_fwd(x, w, bias, lens, B, S):
+    out = torch.empty(B, S, device=x.device, dtype=torch.float32)
+    _lib.call("fs2_rowdot_fwd", _p(x), _p(w), _p(bias), _p(lens), _p(out), B, S, x.shape[-1], dt(x), _stream())
+    return out
+
+
+def rowdot_bwd(x, w, g, lens, dw, db, B, S):
+    dx = torch.empty_like(x)
+    _lib.call("fs2_rowdot_bwd", _p(x), _p(w), _p(g), _p(lens), _p(dx), _p(dw), _p(db), B, S, x.shape[-1], dt(x),
+              _stream())
+    return dx
+
+
+def mask_rows(x, lens, B, S):
+    _lib.call("fs2_mask_rows", _p(x), _p(lens), B, S, x.shape[-1], dt(x), _stream())
+    return x
+
+
+def cast(x, dtype):
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    _lib.call("fs2_cast", _p(x), dt(x), _p(out), dt(dtype), x.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ optimiser
+def sumsq(x, out):
+    _lib.call("fs2_sumsq", _p(x), x.numel(), _p(out), _stream())
+
+
+def adam_step(p, g, m, v, gnorm_sq, max_norm, hyper, b1, b2, eps, wd):
+    _lib.call("fs2_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(gnorm_sq), float(max_norm), _p(hyper), b1, b2,
+              eps, wd, _stream())

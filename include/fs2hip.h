@@ -1,0 +1,132 @@
+/* fs2hip.h — C ABI of libfs2hip.so: hand-written gfx950 (CDNA4) kernels for the FastSpeech 2 hot path.
+ *
+ * The reference (ming024/FastSpeech2) has no FFI layer: its hot path is torch op call sites inside Python
+ * nn.Modules.  Each entry point below replaces the torch ops at the cited reference location (paths relative
+ * to the reference tree).  Host code above this ABI (fastspeech2_amd/*.py) mirrors the reference's Python
+ * surface and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (incl. workspaces);
+ *   - functions enqueue work on `stream` and return immediately: no allocation, no synchronisation,
+ *     no global mutable state (re-entrant; safe from autograd / DDP hook threads);
+ *   - return 0 on success; <0 on error (FS2_EINVAL -1 bad shape/null, FS2_EDTYPE -2, FS2_ELAUNCH -3),
+ *     message via fs2_last_error() (thread-local);
+ *   - dtype: 0 = float32, 1 = bfloat16 (storage of activations / packed weights; accumulation, statistics,
+ *     parameters, gradients of parameters and optimiser state are always float32);
+ *   - activations are time-major rows [B*S][C] with C contiguous (== the reference's (B, S, C) tensors);
+ *   - `lens` (int32 per sequence) replaces the reference's bool masks: row t of sequence b is padding iff
+ *     t >= lens[b] (utils/tools.py:91-99 get_mask_from_lengths).
+ */
+#ifndef FS2HIP_H
+#define FS2HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* fs2_stream_t; /* == hipStream_t */
+
+enum { FS2_F32 = 0, FS2_BF16 = 1 };
+enum { FS2_ACT_NONE = 0, FS2_ACT_RELU = 1, FS2_ACT_TANH = 2, FS2_ACT_LRELU = 3 };
+
+int fs2_version(void);
+const char* fs2_last_error(void);
+
+/* ---- dense contractions (MFMA) -------------------------------------------------------------------- */
+/* Y[m][n] = ((act(sum_{j<taps} sum_c X[m + j*dil - pad][c] * W[n][j][c] + bias[n])) + R[m][n]) * out_scale
+ * (+= Y if accumulate); taps shifted outside their sequence [0,S) contribute 0; rows t >= lens[b] -> 0.
+ * Replaces nn.Linear / nn.Conv1d forward AND data-gradient (with the tap-flipped pack):
+ *   transformer/SubLayers.py:39-41,54 (w_qs/w_ks/w_vs/fc), :87-88 (w_1 k=9, w_2 k=1);
+ *   model/modules.py:209-240,291-296 (VariancePredictor Conv k=3); model/fastspeech2.py:95 (mel_linear);
+ *   transformer/Layers.py:129-137 (PostNet k=5); hifigan/models.py:96-103,150-163; audio/stft.py:66-72. */
+int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Y,
+                  long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad, int act,
+                  float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
+                  fs2_stream_t stream);
+/* torch weight (Cout,Cin,k) f32 -> Wf[n][j][c] (forward) and/or Wd[c][j][n] = W[n][c][k-1-j] (data gradient). */
+int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, fs2_stream_t stream);
+/* dW[n][c][j] += sum_m dY[m][n] * X[m + j*dil - pad][c]   (torch layout (Cout,Cin,k), f32, atomic accumulate) */
+int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int S, int taps,
+                   int dil, int pad, int dtype, fs2_stream_t stream);
+/* out[n] += sum_m x[m][n]  (bias gradients) */
+int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, fs2_stream_t stream);
+
+/* ---- attention: transformer/Modules.py:14-25 + head split/merge SubLayers.py:39-52 ----------------- */
+/* qkv [B*S][3*H*128] = (q|k|v); ctx [B*S][H*128]; lse [B][H][S] f32 (saved for backward). */
+int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_t* lens, int B, int S, int H, int dk, float scale,
+                 int dtype, fs2_stream_t stream);
+/* delta [B][H][S] f32 workspace; dqkv [B*S][3*H*128] receives (dq|dk|dv). */
+int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv,
+                 const int32_t* lens, int B, int S, int H, int dk, float scale, int dtype, fs2_stream_t stream);
+
+/* ---- LayerNorm family: SubLayers.py:54-55,90-91 + Layers.py:25,28; model/modules.py:222-240 -------- */
+/* z = drop_pre(y) + res (written back into y); out = mask(drop_post(LN(z)*gamma+beta)); saves mean/rstd. */
+int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, const int32_t* lens, void* out,
+               float* mean, float* rstd, int B, int S, int C, float eps, float p_pre, uint64_t seed_pre, float p_post,
+               uint64_t seed_post, int dtype, fs2_stream_t stream);
+/* d1 = dz (+ d1_add), d2 = dz * dropmask_pre * (relu_bwd ? z>0 : 1); dgamma/dbeta accumulated atomically. */
+int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
+               const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta, int B, int S,
+               int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, int relu_bwd, int dtype,
+               fs2_stream_t stream);
+
+/* ---- BatchNorm1d (+tanh, +dropout) of PostNet: transformer/Layers.py:129-137 ------------------------ */
+int fs2_bn_stats(const void* x, float* stats /*2C, zeroed*/, int M, int C, int dtype, fs2_stream_t stream);
+int fs2_bn_finalize(const float* stats, float* running_mean, float* running_var, float* mean_rstd /*2C*/, int M, int C,
+                    float eps, float momentum, fs2_stream_t stream);
+int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, void* out, int M, int C,
+                 int act, float p, uint64_t seed, int dtype, fs2_stream_t stream);
+int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
+               float* sums /*2C zeroed: dbeta|dgamma*/, void* dx, int M, int C, int act, float p, uint64_t seed,
+               int dtype, fs2_stream_t stream);
+
+/* ---- gathers / index kernels ----------------------------------------------------------------------- */
+/* transformer/Models.py:89-91: out = src_word_emb[tok] + position_enc[t] */
+int fs2_embed_pe_fwd(const int64_t* tokens, const float* emb, const float* pe, void* out, int B, int L, int C, int V,
+                     int dtype, fs2_stream_t stream);
+int fs2_embed_bwd(const int64_t* tokens, const void* dy, float* demb, int rows, int C, int V, int pad_idx, int dtype,
+                  fs2_stream_t stream);
+/* model/fastspeech2.py:68-71: x[b,t,:] += speaker_emb[speakers[b]] */
+int fs2_add_rowvec(void* x, const float* table, const int64_t* idx, int B, int S, int C, int V, int dtype,
+                   fs2_stream_t stream);
+int fs2_rowvec_bwd(const void* dy, float* dtable, const int64_t* idx, int B, int S, int C, int V, int dtype,
+                   fs2_stream_t stream);
+/* model/modules.py:80-100,121,126: out = x + emb[bucketize(vals*scale, bins)] ; idx_out saved for backward */
+int fs2_bucket_embed_add_fwd(const void* x, const float* vals, float scale, const float* bins, int nbins,
+                             const float* emb, void* out, int32_t* idx_out, int rows, int C, int dtype,
+                             fs2_stream_t stream);
+int fs2_bucket_embed_bwd(const int32_t* idx, const void* dy, float* demb, int rows, int C, int dtype,
+                         fs2_stream_t stream);
+/* model/modules.py:167-194 LengthRegulator (+ utils/tools.py:299-317 pad): integer index map, bit-exact.
+ * cum [B][L+1] int32 exclusive prefix sums of max((int)d,0); idx [B][T] frame->phoneme (-1 = padding);
+ * mel_len [B] int64 = un-cropped total (Appendix A #4). */
+int fs2_lr_index(const void* durations, int dur_is_float, int B, int L, int T, int32_t* cum, int32_t* idx,
+                 int64_t* mel_len, fs2_stream_t stream);
+/* out[b,t,:] = x[b,idx[b,t],:] (0 if idx<0) + (pe ? pe[t,:] : 0)  — pe fuses Decoder's position_enc add
+ * (transformer/Models.py:154-162). */
+int fs2_lr_gather_fwd(const void* x, const int32_t* idx, const float* pe, void* out, int B, int L, int T, int C,
+                      int dtype, fs2_stream_t stream);
+int fs2_lr_gather_bwd(const void* dy, const int32_t* cum, void* dx, int B, int L, int T, int C, int accumulate,
+                      int dtype, fs2_stream_t stream);
+/* model/modules.py:132-135: clamp(round_half_even(exp(log_d)-1) * d_control, min=0) */
+int fs2_duration_round(const float* logd, float d_control, float* out, int n, fs2_stream_t stream);
+/* model/modules.py:243-249: out[r] = mask(dot(x[r,:], w) + b) */
+int fs2_rowdot_fwd(const void* x, const float* w, const float* bias, const int32_t* lens, float* out, int B, int S, int C,
+                   int dtype, fs2_stream_t stream);
+int fs2_rowdot_bwd(const void* x, const float* w, const float* g, const int32_t* lens, void* dx, float* dw, float* db,
+                   int B, int S, int C, int dtype, fs2_stream_t stream);
+/* transformer/Layers.py:25,28 masked_fill(mask, 0) in place */
+int fs2_mask_rows(void* x, const int32_t* lens, int B, int S, int C, int dtype, fs2_stream_t stream);
+int fs2_cast(const void* in, int in_dtype, void* out, int out_dtype, size_t n, fs2_stream_t stream);
+
+/* ---- optimiser: train.py:93 clip_grad_norm_ + model/optimizer.py:10-51 Adam ------------------------- */
+int fs2_sumsq(const float* x, size_t n, float* out /*+=*/, fs2_stream_t stream);
+/* hyper (device) = {lr, 1-beta1^t, 1-beta2^t}; clip = min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) */
+int fs2_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* gnorm_sq, float max_norm,
+                  const float* hyper, float b1, float b2, float eps, float wd, fs2_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,318 @@
+"""Op-level parity: every HIP kernel vs a plain PyTorch fp32/fp64 CPU computation of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from fastspeech2_amd import ops
+    return ops
+
+
+def rel_err(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def conv_ref(x, w, b, S, dil, pad, lens=None):
+    """x: [B*S, Cin] rows; w: (Cout, Cin, k) -> [B*S, Cout] with arbitrary left pad (right pad implied by same length)."""
+    B = x.shape[0] // S
+    k = w.shape[2]
+    xx = x.double().view(B, S, -1).transpose(1, 2)
+    right = (k - 1) * dil - pad
+    xx = F.pad(xx, (pad, max(right, 0)))
+    y = F.conv1d(xx, w.double(), None if b is None else b.double(), dilation=dil)[:, :, :S]
+    y = y.transpose(1, 2).reshape(B * S, -1)
+    if lens is not None:
+        t = torch.arange(S).unsqueeze(0)
+        mask = (t >= lens.unsqueeze(1)).reshape(-1)
+        y[mask] = 0
+    return y
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,S,Cin,Cout,k,dil", [(3, 50, 256, 256, 1, 1), (2, 77, 256, 1024, 9, 1), (2, 130, 80, 512, 5, 1),
+                                                (1, 300, 512, 80, 5, 1), (2, 64, 128, 128, 3, 3), (1, 200, 32, 8, 7, 1),
+                                                (2, 33, 1024, 256, 1, 1), (1, 257, 64, 64, 11, 5)])
+def test_conv_gemm_fwd(dev, dtype, tol, B, S, Cin, Cout, k, dil):
+    ops = _ops()
+    torch.manual_seed(0)
+    x = torch.randn(B * S, Cin)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    b = torch.randn(Cout)
+    pad = dil * (k - 1) // 2
+    lens = torch.tensor([S - 7 * i for i in range(B)], dtype=torch.int32)
+    xd = x.to(dev).to(dtype)
+    wf, wd = ops.pack_weight(w.to(dev), dtype)
+    xr = xd.float().cpu()
+    wr = wf.float().cpu().permute(0, 2, 1).contiguous()
+    for use_lens in (False, True):
+        y = ops.conv_gemm(xd, wf, b.to(dev), S, taps=k, dil=dil, pad=pad, act=ops.ACT_RELU,
+                          lens=lens.to(dev) if use_lens else None)
+        ref = torch.relu(conv_ref(xr, wr, b, S, dil, pad)).clone()
+        if use_lens:
+            t = torch.arange(S).unsqueeze(0)
+            ref[(t >= lens.unsqueeze(1)).reshape(-1)] = 0
+        assert rel_err(y.float(), ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,S,Cin,Cout,k,dil", [(2, 70, 256, 1024, 9, 1), (2, 61, 256, 256, 3, 1), (1, 140, 80, 512, 5, 1),
+                                                (3, 40, 256, 768, 1, 1), (1, 300, 512, 80, 5, 1)])
+def test_conv_grads(dev, dtype, tol, B, S, Cin, Cout, k, dil):
+    ops = _ops()
+    torch.manual_seed(1)
+    pad = dil * (k - 1) // 2
+    x = torch.randn(B * S, Cin)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    dy = torch.randn(B * S, Cout)
+    xd, dyd = x.to(dev).to(dtype), dy.to(dev).to(dtype)
+    wf, wd = ops.pack_weight(w.to(dev), dtype)
+    xr = xd.float().cpu().double().requires_grad_(True)
+    wr = wf.float().cpu().permute(0, 2, 1).contiguous().double().requires_grad_(True)
+    y = conv_ref(xr, wr, None, S, dil, pad)
+    y.backward(dyd.float().cpu().double())
+    # dgrad: conv of dy with tap-flipped transposed weights, pad' = (k-1)*dil - pad
+    dx = ops.conv_gemm(dyd, wd, None, S, taps=k, dil=dil, pad=(k - 1) * dil - pad)
+    assert rel_err(dx.float(), xr.grad) < tol
+    dw = torch.zeros(Cout, Cin, k, device=dev)
+    ops.conv_wgrad(dyd, xd, dw, S, taps=k, dil=dil, pad=pad)
+    assert rel_err(dw, wr.grad) < (tol if dtype == torch.float32 else 2e-2)
+    db = torch.zeros(Cout, device=dev)
+    ops.colsum(dyd, db)
+    assert rel_err(db, dyd.float().cpu().double().sum(0)) < 1e-4
+
+
+def attn_ref(qkv, lens, B, S, H):
+    dk = 128
+    q, k, v = qkv.view(B, S, 3, H, dk).unbind(2)
+    q, k, v = [t.permute(0, 2, 1, 3) for t in (q, k, v)]  # B,H,S,dk
+    s = q @ k.transpose(-1, -2) / math.sqrt(dk)
+    mask = torch.arange(S).view(1, 1, 1, S) >= lens.view(B, 1, 1, 1)
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * S, H * dk)
+    return o
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,S,H", [(2, 100, 2), (3, 257, 2), (1, 31, 1), (2, 640, 2)])
+def test_attention(dev, dtype, tol, B, S, H):
+    ops = _ops()
+    torch.manual_seed(2)
+    qkv = torch.randn(B * S, 3 * H * 128)
+    lens = torch.tensor([S - 13 * i for i in range(B)], dtype=torch.int32)
+    qd = qkv.to(dev).to(dtype)
+    qr = qd.float().cpu().double().requires_grad_(True)
+    ref = attn_ref(qr, lens, B, S, H)
+    ctx, lse = ops.attn_fwd(qd, lens.to(dev), B, S, H)
+    valid = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).reshape(-1)
+    assert rel_err(ctx.float().cpu()[valid], ref.detach()[valid]) < tol
+    dctx = torch.randn(B * S, H * 128)
+    dctx[~valid] = 0
+    dd = dctx.to(dev).to(dtype)
+    ref.backward(dd.float().cpu().double())
+    dqkv = ops.attn_bwd(qd, ctx, dd, lse, lens.to(dev), B, S, H)
+    g = qr.grad.clone()
+    assert rel_err(dqkv.float(), g) < (tol * 3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_layernorm(dev, dtype, tol):
+    ops = _ops()
+    torch.manual_seed(3)
+    B, S, C = 3, 45, 256
+    y = torch.randn(B * S, C); res = torch.randn(B * S, C)
+    gamma = torch.randn(C); beta = torch.randn(C)
+    lens = torch.tensor([45, 30, 17], dtype=torch.int32)
+    yd, rd = y.to(dev).to(dtype), res.to(dev).to(dtype)
+    yr = yd.float().cpu().double().requires_grad_(True)
+    rr = rd.float().cpu().double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    z = yr + rr
+    if dtype == torch.bfloat16:
+        z = z + (z.detach().float().bfloat16().double() - z.detach())   # kernel normalises the stored (rounded) z
+    ref = F.layer_norm(z, (C,), gr, br, 1e-5)
+    pad = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).reshape(-1)
+    ref = ref.masked_fill(pad.unsqueeze(1), 0)
+    out, mean, rstd = ops.ln_fwd(yd, rd, gamma.to(dev), beta.to(dev), lens.to(dev), B, S)
+    assert rel_err(out.float(), ref.detach()) < tol
+    dout = torch.randn(B * S, C)
+    dd = dout.to(dev).to(dtype)
+    ref.backward(dd.float().cpu().double())
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    d1, _ = ops.ln_bwd(yd, dd, gamma.to(dev), lens.to(dev), mean, rstd, dg, db, B, S)
+    assert rel_err(d1.float(), yr.grad) < tol * 2
+    assert rel_err(dg, gr.grad) < tol * 2
+    assert rel_err(db, br.grad) < tol * 2
+
+
+def test_layernorm_dropout_consistency(dev):
+    """dropout masks are regenerated in backward: zero pattern of d2 must equal the forward keep-mask."""
+    ops = _ops()
+    torch.manual_seed(4)
+    B, S, C = 2, 40, 256
+    y = torch.randn(B * S, C, device=dev) + 3.0
+    res = torch.zeros(B * S, C, device=dev)
+    g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+    y0 = y.clone()
+    out, mean, rstd = ops.ln_fwd(y, res, g, b, None, B, S, p_pre=0.2, seed_pre=1234)
+    keep = (y != 0)                       # y now holds z = drop(y0)
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.8) < 0.02
+    assert torch.allclose(y[keep], y0[keep] / 0.8, rtol=1e-6)
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    dout = torch.randn(B * S, C, device=dev)
+    d1, d2 = ops.ln_bwd(y, dout, g, None, mean, rstd, dg, db, B, S, want_d2=True, p_pre=0.2, seed_pre=1234)
+    assert torch.equal(d2 != 0, keep & (d1 != 0))
+    assert torch.allclose(d2[keep], d1[keep] / 0.8, rtol=1e-6)
+    # post-LN dropout + relu backward (variance predictor form)
+    y = torch.relu(torch.randn(B * S, C, device=dev))
+    out, mean, rstd = ops.ln_fwd(y, None, g, b, None, B, S, p_post=0.5, seed_post=77)
+    keep = out != 0
+    assert abs(keep.float().mean().item() - 0.5) < 0.03
+    ref = F.layer_norm(y, (C,)) * 2.0
+    assert torch.allclose(out[keep], ref[keep], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_batchnorm(dev, dtype, tol):
+    ops = _ops()
+    torch.manual_seed(5)
+    M, C = 700, 512
+    x = torch.randn(M, C) * 2 + 0.5
+    gamma = torch.rand(C) + 0.5; beta = torch.randn(C) * 0.1
+    xd = x.to(dev).to(dtype)
+    xr = xd.float().cpu().double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    rm = torch.zeros(C, dtype=torch.double); rv = torch.ones(C, dtype=torch.double)
+    ref = torch.tanh(F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5))
+    rmd = torch.zeros(C, device=dev); rvd = torch.ones(C, device=dev)
+    out, mean_rstd = ops.bn_train_fwd(xd, gamma.to(dev), beta.to(dev), rmd, rvd, ops.ACT_TANH, 0.0, 0)
+    assert rel_err(out.float(), ref.detach()) < tol
+    assert rel_err(rmd, rm) < 1e-4 and rel_err(rvd, rv) < 1e-4
+    dout = torch.randn(M, C)
+    dd = dout.to(dev).to(dtype)
+    ref.backward(dd.float().cpu().double())
+    dx, dgam, dbet = ops.bn_bwd(xd, dd, mean_rstd, gamma.to(dev), beta.to(dev), ops.ACT_TANH, 0.0, 0)
+    assert rel_err(dx.float(), xr.grad) < tol * 3
+    assert rel_err(dgam, gr.grad) < tol * 3
+    assert rel_err(dbet, br.grad) < tol * 3
+
+
+def lr_ref(x, dur, max_len):
+    """Restatement of reference LengthRegulator (model/modules.py:167-194) in plain python."""
+    outs, lens = [], []
+    for xb, db in zip(x, dur):
+        rows = []
+        for i in range(xb.shape[0]):
+            n = max(int(db[i].item()), 0)
+            rows.append(xb[i:i + 1].expand(n, -1))
+        e = torch.cat(rows, 0)
+        lens.append(e.shape[0])
+        if e.shape[0] >= max_len:
+            e = e[:max_len]
+        else:
+            e = F.pad(e, (0, 0, 0, max_len - e.shape[0]))
+        outs.append(e)
+    return torch.stack(outs), torch.tensor(lens, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("is_float", [False, True])
+def test_length_regulator_bit_exact(dev, is_float):
+    ops = _ops()
+    torch.manual_seed(6)
+    B, L, C = 4, 37, 256
+    x = torch.randn(B, L, C)
+    if is_float:
+        dur = (torch.rand(B, L) * 9 - 1.0)           # includes negatives and fractions (trunc toward zero)
+        dur[0, 3] = 2.5; dur[0, 4] = -0.5; dur[1, 0] = 0.999
+    else:
+        dur = torch.randint(0, 10, (B, L))
+    dur[2, 20:] = 0
+    for T in (int(dur.clamp(min=0).long().sum(1).max().item()), 150, 60):
+        ref, ref_len = lr_ref(x, dur, T)
+        cum, idx, mel_len = ops.lr_index(dur.to(dev), T)
+        out = ops.lr_gather_fwd(x.to(dev).view(B * L, C), idx, None, B, L, T)
+        assert torch.equal(mel_len.cpu(), ref_len)
+        assert torch.equal(out.cpu().view(B, T, C), ref)          # payload copied verbatim: bit-exact
+        # backward = segment sum
+        dy = torch.randn(B, T, C)
+        xr = x.clone().requires_grad_(True)
+        r2, _ = lr_ref(xr, dur, T)
+        r2.backward(dy)
+        dx = ops.lr_gather_bwd(dy.to(dev).view(B * T, C), cum, B, L, T)
+        assert torch.allclose(dx.cpu().view(B, L, C), xr.grad, atol=1e-5)
+
+
+def test_embed_bucket_rowdot(dev):
+    ops = _ops()
+    torch.manual_seed(7)
+    B, L, C, V = 3, 20, 256, 361
+    tok = torch.randint(1, V, (B, L)); tok[1, 15:] = 0
+    emb = torch.randn(V, C); emb[0] = 0
+    pe = torch.randn(64, C)
+    out = ops.embed_pe_fwd(tok.to(dev), emb.to(dev), pe.to(dev), torch.float32)
+    ref = emb[tok] + pe[:L].unsqueeze(0)
+    assert torch.equal(out.cpu().view(B, L, C), ref)
+    dy = torch.randn(B * L, C)
+    demb = torch.zeros(V, C, device=dev)
+    ops.embed_bwd(tok.to(dev), dy.to(dev), demb)
+    r = torch.zeros(V, C).index_add_(0, tok.view(-1), dy); r[0] = 0
+    assert torch.allclose(demb.cpu(), r, atol=1e-5)
+    # bucketize
+    bins = torch.linspace(-2.9, 11.3, 255)
+    vals = torch.cat([torch.randn(B * L - 4) * 3, bins[[0, 10, 254]], torch.tensor([100.0])])
+    table = torch.randn(256, C)
+    x = torch.randn(B * L, C)
+    o, idx = ops.bucket_embed_add_fwd(x.to(dev), vals.to(dev), 1.0, bins.to(dev), table.to(dev))
+    ridx = torch.bucketize(vals, bins)
+    assert torch.equal(idx.cpu().long(), ridx)
+    assert torch.equal(o.cpu(), x + table[ridx])
+    # rowdot
+    w = torch.randn(C); bb = torch.randn(1)
+    lens = torch.tensor([20, 11, 5], dtype=torch.int32)
+    y = ops.rowdot_fwd(x.to(dev), w.to(dev), bb.to(dev), lens.to(dev), B, L)
+    pad = torch.arange(L).unsqueeze(0) >= lens.unsqueeze(1)
+    ry = (x @ w + bb).view(B, L).masked_fill(pad, 0)
+    assert torch.allclose(y.cpu(), ry, atol=1e-4)
+    g = torch.randn(B, L)
+    dw = torch.zeros(C, device=dev); db = torch.zeros(1, device=dev)
+    dx = ops.rowdot_bwd(x.to(dev), w.to(dev), g.to(dev), lens.to(dev), dw, db, B, L)
+    gm = g.masked_fill(pad, 0).view(-1)
+    assert torch.allclose(dx.cpu(), gm.unsqueeze(1) * w, atol=1e-5)
+    assert torch.allclose(dw.cpu(), gm @ x, atol=1e-3)
+    assert torch.allclose(db.cpu(), gm.sum().view(1), atol=1e-4)
+
+
+def test_duration_round(dev):
+    ops = _ops()
+    logd = torch.log(torch.tensor([1.5, 2.5, 3.5, 4.5, 0.2, 1.0, 7.49, 7.51]) + 1)
+    for ctl in (1.0, 0.8, 1.3):
+        out = ops.duration_round(logd.to(dev), ctl).cpu()
+        ref = torch.clamp(torch.round(torch.exp(logd) - 1) * ctl, min=0)
+        assert torch.equal(out, ref)
+
+
+def test_adam_matches_torch(dev):
+    ops = _ops()
+    torch.manual_seed(8)
+    n = 10007 * 4
+    p = torch.randn(n); g = torch.randn(n) * 3
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        pr.grad = g.clone() * step
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = (g * step).to(dev)
+        nsq = torch.zeros(1, device=dev)
+        ops.sumsq(gd, nsq)
+        hyper = torch.tensor([1e-3, 1 - 0.9 ** step, 1 - 0.98 ** step], device=dev)
+        ops.adam_step(pd, gd, m, v, nsq, 1.0, hyper, 0.9, 0.98, 1e-9, 0.0)
+    assert torch.allclose(pd.cpu(), pr.detach(), atol=2e-6)
