@@ -14,7 +14,7 @@
 #define FS2_ELAUNCH (-3)   // hip launch failure
 
 enum { FS2_F32 = 0, FS2_BF16 = 1 };
-enum { FS2_ACT_NONE = 0, FS2_ACT_RELU = 1, FS2_ACT_TANH = 2, FS2_ACT_LRELU = 3 };
+enum { FS2_ACT_NONE = 0, FS2_ACT_RELU = 1, FS2_ACT_TANH = 2, FS2_ACT_LRELU = 3, FS2_ACT_GATE = 4 };
 
 void fs2_set_error(const char* fmt, ...);
 

@@ -436,3 +436,52 @@ extern "C" int fs2_cast(const void* in, int in_dtype, void* out, int out_dtype, 
     FS2_CHECK_LAUNCH("cast");
     return FS2_OK;
 }
+
+// ------------------------------------------------------------------ small elementwise helpers
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 x = ld4<T>(a + i * 4), y = ld4<T>(b + i * 4);
+        st4<T>(out + i * 4, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+    }
+}
+extern "C" int fs2_add(const void* a, const void* b, void* out, size_t n, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(a && b && out, "add: null pointer");
+    FS2_CHECK_ARG((n % 4) == 0, "add: n%%4");
+    if (n == 0) return FS2_OK;
+    size_t n4 = n / 4;
+    int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    DISPATCH_DTYPE(dtype, add_kernel<T><<<grid, 256, 0, stream>>>((const T*)a, (const T*)b, (T*)out, n4));
+    FS2_CHECK_LAUNCH("add");
+    return FS2_OK;
+}
+// x[b,t,:] += pe[t,:]   (Decoder position_enc add when it cannot be fused into the LengthRegulator gather)
+template <typename T>
+__global__ void add_pe_kernel(T* __restrict__ x, const float* __restrict__ pe, int rows, int S, int C) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    int t = row % S;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 a = ld4<T>(x + (size_t)row * C + c);
+        float4 p = *reinterpret_cast<const float4*>(pe + (size_t)t * C + c);
+        st4<T>(x + (size_t)row * C + c, make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w));
+    }
+}
+extern "C" int fs2_add_pe(void* x, const float* pe, int B, int S, int C, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && pe, "add_pe: null pointer");
+    FS2_CHECK_ARG((C % 4) == 0, "add_pe: C%%4");
+    int rows = B * S;
+    if (rows == 0) return FS2_OK;
+    DISPATCH_DTYPE(dtype, add_pe_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>((T*)x, pe, rows, S, C));
+    FS2_CHECK_LAUNCH("add_pe");
+    return FS2_OK;
+}
+// device-resident step counter (dropout seed offset): *ctr += inc, inside the captured step graph.
+__global__ void bump_kernel(uint64_t* ctr, uint64_t inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += inc; }
+extern "C" int fs2_bump_counter(uint64_t* ctr, uint64_t inc, hipStream_t stream) {
+    FS2_CHECK_ARG(ctr, "bump_counter: null pointer");
+    bump_kernel<<<1, 64, 0, stream>>>(ctr, inc);
+    FS2_CHECK_LAUNCH("bump_counter");
+    return FS2_OK;
+}

@@ -218,7 +218,11 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
                 int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= a.M) continue;
                 float v = apply_act(acc[mb][nb][r] + bv, a.act, a.slope);
-                if (R) v += Elem<T>::ld(R + (size_t)m * a.ldr + n);
+                if (R) {
+                    float rv = Elem<T>::ld(R + (size_t)m * a.ldr + n);
+                    if (a.act == FS2_ACT_GATE) v = rv > 0.f ? v : 0.f;   // ReLU backward gate: R holds the ReLU output
+                    else v += rv;
+                }
                 v *= a.out_scale;
                 if (a.lens) {
                     int b = m / a.S;

@@ -18,6 +18,7 @@ struct LnArgs {
     float eps;
     float p_pre, p_post;   // dropout before the residual add / after the LayerNorm
     uint64_t seed_pre, seed_post;
+    const uint64_t* seed_dev;   // optional device-resident per-step seed offset (keeps hipGraph replays fresh)
 };
 
 template <typename T>
@@ -30,6 +31,7 @@ __global__ void ln_fwd_kernel(LnArgs a) {
     T* out = reinterpret_cast<T*>(a.out) + (size_t)row * a.C;
     float4 v[FS2_LN_MAXV];
     const float ik_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+    if (a.seed_dev) { uint64_t o = *a.seed_dev; a.seed_pre += o; a.seed_post += o; }
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < FS2_LN_MAXV; ++i) {
@@ -95,13 +97,14 @@ __global__ void ln_fwd_kernel(LnArgs a) {
 
 extern "C" int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, const int32_t* lens, void* out,
                           float* mean, float* rstd, int B, int S, int C, float eps, float p_pre, uint64_t seed_pre,
-                          float p_post, uint64_t seed_post, int dtype, hipStream_t stream) {
+                          float p_post, uint64_t seed_post, const uint64_t* seed_dev, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(y && gamma && beta && out && mean && rstd, "ln_fwd: null pointer");
     FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * FS2_LN_MAXV, "ln_fwd: unsupported C=%d", C);
     FS2_CHECK_ARG(p_pre < 1.f && p_post < 1.f, "ln_fwd: dropout p must be < 1");
     LnArgs a;
     a.y = y; a.res = res; a.gamma = gamma; a.beta = beta; a.lens = lens; a.out = out; a.mean = mean; a.rstd = rstd;
     a.rows = B * S; a.S = S; a.C = C; a.eps = eps; a.p_pre = p_pre; a.p_post = p_post; a.seed_pre = seed_pre; a.seed_post = seed_post;
+    a.seed_dev = seed_dev;
     if (a.rows == 0) return FS2_OK;
     if (dtype == FS2_F32) ln_fwd_kernel<float><<<fs2_cdiv(a.rows, 4), 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) ln_fwd_kernel<bf16_t><<<fs2_cdiv(a.rows, 4), 256, 0, stream>>>(a);
@@ -123,6 +126,7 @@ struct LnBwdArgs {
     float* dgamma; float* dbeta;
     int rows, S, C;
     float p_pre, p_post; uint64_t seed_pre, seed_post;
+    const uint64_t* seed_dev;
     int relu_bwd;
 };
 
@@ -135,6 +139,7 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
     for (int i = 0; i < FS2_LN_MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
     const float ik_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
     const float ik_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+    if (a.seed_dev) { uint64_t o = *a.seed_dev; a.seed_pre += o; a.seed_post += o; }
     for (int row = blockIdx.x * 4 + w; row < a.rows; row += gridDim.x * 4) {
         bool pad = false;
         if (a.lens) { int b = row / a.S; pad = (row - b * a.S) >= a.lens[b]; }
@@ -234,8 +239,8 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
 
 extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
                           const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta, int B,
-                          int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, int relu_bwd,
-                          int dtype, hipStream_t stream) {
+                          int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
+                          const uint64_t* seed_dev, int relu_bwd, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(z && dout && gamma && mean && rstd && dgamma && dbeta, "ln_bwd: null pointer");
     FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * FS2_LN_MAXV, "ln_bwd: unsupported C=%d", C);
     // the wave-uniform early break in the reduction requires whole 256-channel groups
@@ -243,7 +248,7 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     LnBwdArgs a;
     a.z = z; a.dout = dout; a.gamma = gamma; a.lens = lens; a.mean = mean; a.rstd = rstd; a.d1_add = d1_add; a.d1 = d1; a.d2 = d2;
     a.dgamma = dgamma; a.dbeta = dbeta; a.rows = B * S; a.S = S; a.C = C; a.p_pre = p_pre; a.p_post = p_post;
-    a.seed_pre = seed_pre; a.seed_post = seed_post; a.relu_bwd = relu_bwd;
+    a.seed_pre = seed_pre; a.seed_post = seed_post; a.seed_dev = seed_dev; a.relu_bwd = relu_bwd;
     if (a.rows == 0) return FS2_OK;
     int grid = fs2_cdiv(a.rows, 4);
     if (grid > 1024) grid = 1024;
@@ -326,9 +331,10 @@ extern "C" int fs2_bn_finalize(const float* stats, float* running_mean, float* r
 // out = drop(act((x-mean)*rstd*gamma+beta))
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, T* __restrict__ out, size_t total4, int C, int act, float p,
-                                uint64_t seed) {
+                                const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ out, size_t total4,
+                                int C, int act, float p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
     const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    if (seed_dev) seed += *seed_dev;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         size_t e = i * 4;
         int c = (int)(e % C);
@@ -341,18 +347,20 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
             if (p > 0.f) o *= fs2_drop_scale(seed, (uint32_t)(e + k), p, ik);
             vv[k] = o;
         }
+        if (res) { float4 r = ld4<T>(res + e); vv[0] += r.x; vv[1] += r.y; vv[2] += r.z; vv[3] += r.w; }
         st4<T>(out + e, make_float4(vv[0], vv[1], vv[2], vv[3]));
     }
 }
-extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, void* out, int M,
-                            int C, int act, float p, uint64_t seed, int dtype, hipStream_t stream) {
+extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, const void* res,
+                            void* out, int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
+                            hipStream_t stream) {
     FS2_CHECK_ARG(x && mean_rstd && gamma && beta && out, "bn_apply: null pointer");
     FS2_CHECK_ARG(C % 4 == 0, "bn_apply: C%%4");
     size_t total4 = (size_t)M * C / 4;
     if (total4 == 0) return FS2_OK;
     int grid = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-    if (dtype == FS2_F32) bn_apply_kernel<float><<<grid, 256, 0, stream>>>((const float*)x, mean_rstd, gamma, beta, (float*)out, total4, C, act, p, seed);
-    else if (dtype == FS2_BF16) bn_apply_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)out, total4, C, act, p, seed);
+    if (dtype == FS2_F32) bn_apply_kernel<float><<<grid, 256, 0, stream>>>((const float*)x, mean_rstd, gamma, beta, (const float*)res, (float*)out, total4, C, act, p, seed, seed_dev);
+    else if (dtype == FS2_BF16) bn_apply_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)res, (bf16_t*)out, total4, C, act, p, seed, seed_dev);
     else { fs2_set_error("bn_apply: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("bn_apply");
     return FS2_OK;
@@ -363,8 +371,10 @@ extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* 
 template <typename T, int PASS>
 __global__ void bn_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ mean_rstd,
                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sums,
-                              T* __restrict__ dx, int M, int C, int rows_per_block, int act, float p, uint64_t seed) {
+                              T* __restrict__ dx, int M, int C, int rows_per_block, int act, float p, uint64_t seed,
+                              const uint64_t* __restrict__ seed_dev) {
     __shared__ float s[2][4][64];
+    if (seed_dev) seed += *seed_dev;
     int col = blockIdx.x * 64 + (threadIdx.x & 63);
     int w = threadIdx.x >> 6;
     int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
@@ -395,17 +405,18 @@ __global__ void bn_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dou
 }
 // sums (2C floats, zeroed by the caller) receives dbeta (first C) and dgamma (last C).
 extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
-                          float* sums, void* dx, int M, int C, int act, float p, uint64_t seed, int dtype, hipStream_t stream) {
+                          float* sums, void* dx, int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev,
+                          int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && dout && mean_rstd && gamma && beta && sums && dx, "bn_bwd: null pointer");
     int rpb = 128;
     dim3 grid(fs2_cdiv(C, 64), fs2_cdiv(M, rpb));
     if (M == 0) return FS2_OK;
     if (dtype == FS2_F32) {
-        bn_bwd_kernel<float, 1><<<grid, 256, 0, stream>>>((const float*)x, (const float*)dout, mean_rstd, gamma, beta, sums, (float*)dx, M, C, rpb, act, p, seed);
-        bn_bwd_kernel<float, 2><<<grid, 256, 0, stream>>>((const float*)x, (const float*)dout, mean_rstd, gamma, beta, sums, (float*)dx, M, C, rpb, act, p, seed);
+        bn_bwd_kernel<float, 1><<<grid, 256, 0, stream>>>((const float*)x, (const float*)dout, mean_rstd, gamma, beta, sums, (float*)dx, M, C, rpb, act, p, seed, seed_dev);
+        bn_bwd_kernel<float, 2><<<grid, 256, 0, stream>>>((const float*)x, (const float*)dout, mean_rstd, gamma, beta, sums, (float*)dx, M, C, rpb, act, p, seed, seed_dev);
     } else if (dtype == FS2_BF16) {
-        bn_bwd_kernel<bf16_t, 1><<<grid, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)dout, mean_rstd, gamma, beta, sums, (bf16_t*)dx, M, C, rpb, act, p, seed);
-        bn_bwd_kernel<bf16_t, 2><<<grid, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)dout, mean_rstd, gamma, beta, sums, (bf16_t*)dx, M, C, rpb, act, p, seed);
+        bn_bwd_kernel<bf16_t, 1><<<grid, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)dout, mean_rstd, gamma, beta, sums, (bf16_t*)dx, M, C, rpb, act, p, seed, seed_dev);
+        bn_bwd_kernel<bf16_t, 2><<<grid, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)dout, mean_rstd, gamma, beta, sums, (bf16_t*)dx, M, C, rpb, act, p, seed, seed_dev);
     } else { fs2_set_error("bn_bwd: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("bn_bwd");
     return FS2_OK;

@@ -1,0 +1,458 @@
+"""Hand-scheduled forward / backward of FastSpeech 2 over the HIP kernel library (no autograd tape inside).
+
+The reference gets its backward from torch autograd over ~400 small ATen ops per step
+(reference model/fastspeech2.py:43-110 and everything it calls).  Here the whole model is ONE autograd node:
+`Engine.forward` launches the fused kernels in order and keeps exactly the activations the hand-written
+backward needs; `Engine.backward` launches the gradient kernels in reverse and accumulates parameter
+gradients straight into the flat gradient buffer (so gradient exchange and the optimiser see contiguous
+memory).  All launches go to the current HIP stream with static shapes -> the full step is hipGraph-capturable.
+
+Activation layout: time-major rows [B*S, C]; padding handled by per-sequence lengths (int32), never by masks.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_GATE, ACT_NONE, ACT_RELU, ACT_TANH
+
+_GOLD = 0x9E3779B97F4A7C15
+
+
+def _site_seed(i):
+    return (i * _GOLD + 0x1234567) & 0x7FFFFFFFFFFFFFFF
+
+
+class _Saved:
+    pass
+
+
+class Engine:
+    def __init__(self, model, device):
+        self.m = model
+        self.device = device
+        self.cdt = model.compute_dtype
+        self.weights_dirty = True
+        self._packed = {}
+        self._pe_cache = {}
+        self.seed_counter = torch.zeros(1, device=device, dtype=torch.int64)
+        self.base_seed = 0
+        mc = model.model_config
+        self.tc = mc["transformer"]
+        self.d = self.tc["encoder_hidden"]
+        self.max_seq_len = mc["max_seq_len"]
+        self.vp = mc["variance_predictor"]
+        self.P = dict(model.named_parameters())
+        self.Bf = dict(model.named_buffers())
+        self.G = None   # name -> grad view (built lazily)
+
+    # ------------------------------------------------------------------ weights
+    def _flat_view(self, first_name, numel, shape, grad=False):
+        o = self.m._flat_offsets[first_name]
+        buf = self.m._flat_grad if grad else self.m._flat
+        return buf[o:o + numel].view(shape)
+
+    def _conv_list(self):
+        """(key, weight tensor view (Cout,Cin,k), bias view) for every contraction of the model."""
+        d = self.d
+        out = []
+
+        def fft(prefix):
+            a = prefix + "slf_attn."
+            out.append((a + "qkv", self._flat_view(a + "w_qs.weight", 3 * d * d, (3 * d, d, 1)),
+                        self._flat_view(a + "w_qs.bias", 3 * d, (3 * d,))))
+            out.append((a + "fc", self.P[a + "fc.weight"], self.P[a + "fc.bias"]))
+            f = prefix + "pos_ffn."
+            out.append((f + "w_1", self.P[f + "w_1.weight"], self.P[f + "w_1.bias"]))
+            out.append((f + "w_2", self.P[f + "w_2.weight"], self.P[f + "w_2.bias"]))
+
+        for i in range(self.tc["encoder_layer"]):
+            fft(f"encoder.layer_stack.{i}.")
+        for i in range(self.tc["decoder_layer"]):
+            fft(f"decoder.layer_stack.{i}.")
+        for kind in ("duration", "pitch", "energy"):
+            pre = f"variance_adaptor.{kind}_predictor.conv_layer."
+            out.append((pre + "conv1d_1", self.P[pre + "conv1d_1.conv.weight"], self.P[pre + "conv1d_1.conv.bias"]))
+            out.append((pre + "conv1d_2", self.P[pre + "conv1d_2.conv.weight"], self.P[pre + "conv1d_2.conv.bias"]))
+        out.append(("mel_linear", self.P["mel_linear.weight"], self.P["mel_linear.bias"]))
+        for i in range(5):
+            pre = f"postnet.convolutions.{i}.0.conv"
+            out.append((pre, self.P[pre + ".weight"], self.P[pre + ".bias"]))
+        return out
+
+    def weights(self, need_dgrad):
+        """Packed compute-dtype copies of every weight: Wf[n][tap][c] (+ Wd[c][tap][n] for data gradients)."""
+        if not self.weights_dirty and self._packed and (self._packed_has_dgrad or not need_dgrad):
+            return self._packed
+        packed = {}
+        for key, w, b in self._conv_list():
+            prev = self._packed.get(key)
+            wf = prev[0] if prev is not None else None
+            wd = prev[1] if (prev is not None and prev[1] is not None) else None
+            wf, wd = ops.pack_weight(w, self.cdt, want_fwd=True, want_dgrad=need_dgrad, wf=wf, wd=wd if need_dgrad else None)
+            packed[key] = (wf, wd if need_dgrad else (prev[1] if prev is not None else None), b, w.shape)
+        self._packed = packed
+        self._packed_has_dgrad = need_dgrad
+        self.weights_dirty = False
+        return packed
+
+    def _grads(self):
+        if self.G is None:
+            G = {}
+            for n in self.m._flat_names:
+                G[n] = self.m.grad_view(n)
+            d = self.d
+            for pre in [f"encoder.layer_stack.{i}.slf_attn." for i in range(self.tc["encoder_layer"])] + \
+                       [f"decoder.layer_stack.{i}.slf_attn." for i in range(self.tc["decoder_layer"])]:
+                G[pre + "qkv.weight"] = self._flat_view(pre + "w_qs.weight", 3 * d * d, (3 * d, d, 1), grad=True)
+                G[pre + "qkv.bias"] = self._flat_view(pre + "w_qs.bias", 3 * d, (3 * d,), grad=True)
+            self.G = G
+        return self.G
+
+    def _pe(self, table_param, n):
+        """position table rows [0, n): the parameter while n fits, regenerated sinusoid otherwise
+        (reference transformer/Models.py:82-91,145-162)."""
+        tab = table_param[0]
+        if n <= tab.shape[0]:
+            return tab
+        key = (n, tab.shape[1])
+        if key not in self._pe_cache:
+            from .model import sinusoid_table
+            self._pe_cache[key] = sinusoid_table(n, tab.shape[1]).to(self.device)
+        return self._pe_cache[key]
+
+    # ------------------------------------------------------------------ building blocks
+    def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
+        wf, _, b, shape = W[key]
+        return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res)
+
+    def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None):
+        """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
+        _, wd, _, shape = W[key]
+        return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res)
+
+    def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0):
+        ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad)
+        ops.colsum(dy, gb)
+
+    def _fft_fwd(self, W, pre, x, lens, B, S, n_head, p, seed_dev, site, keep):
+        ks = self.tc["conv_kernel_size"]
+        a, f = pre + "slf_attn.", pre + "pos_ffn."
+        sv = _Saved()
+        qkv = self._gemm(W, a + "qkv", x, S)
+        ctx, lse = ops.attn_fwd(qkv, lens, B, S, n_head, self.d // n_head)
+        y1 = self._gemm(W, a + "fc", ctx, S)
+        h, mean1, rstd1 = ops.ln_fwd(y1, x, self.P[a + "layer_norm.weight"], self.P[a + "layer_norm.bias"], lens, B, S,
+                                     p_pre=p, seed_pre=_site_seed(site), seed_dev=seed_dev)
+        hid = self._gemm(W, f + "w_1", h, S, taps=ks[0], pad=(ks[0] - 1) // 2, act=ACT_RELU,
+                         lens=lens if ks[1] == 1 else None)
+        y2 = self._gemm(W, f + "w_2", hid, S, taps=ks[1], pad=(ks[1] - 1) // 2)
+        out, mean2, rstd2 = ops.ln_fwd(y2, h, self.P[f + "layer_norm.weight"], self.P[f + "layer_norm.bias"], lens, B, S,
+                                       p_pre=p, seed_pre=_site_seed(site + 1), seed_dev=seed_dev)
+        if keep:
+            sv.x, sv.qkv, sv.ctx, sv.lse, sv.z1, sv.mean1, sv.rstd1 = x, qkv, ctx, lse, y1, mean1, rstd1
+            sv.h, sv.hid, sv.z2, sv.mean2, sv.rstd2 = h, hid, y2, mean2, rstd2
+            sv.p, sv.site = p, site
+        return out, sv
+
+    def _fft_bwd(self, W, G, pre, sv, dout, lens, B, S, n_head, seed_dev):
+        ks = self.tc["conv_kernel_size"]
+        a, f = pre + "slf_attn.", pre + "pos_ffn."
+        p = sv.p
+        dz2, dy2 = ops.ln_bwd(sv.z2, dout, self.P[f + "layer_norm.weight"], lens, sv.mean2, sv.rstd2,
+                              G[f + "layer_norm.weight"], G[f + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
+                              p_pre=p, seed_pre=_site_seed(sv.site + 1), seed_dev=seed_dev)
+        if dy2 is None:
+            dy2 = dz2
+        self._wgrad(G[f + "w_2.weight"], G[f + "w_2.bias"], dy2, sv.hid, S, taps=ks[1], pad=(ks[1] - 1) // 2)
+        dhid = self._dgemm(W, f + "w_2", dy2, S, taps=ks[1], pad=(ks[1] - 1) // 2, act=ACT_GATE, res=sv.hid)
+        self._wgrad(G[f + "w_1.weight"], G[f + "w_1.bias"], dhid, sv.h, S, taps=ks[0], pad=(ks[0] - 1) // 2)
+        dh = self._dgemm(W, f + "w_1", dhid, S, taps=ks[0], pad=(ks[0] - 1) // 2, res=dz2)
+        dz1, dy1 = ops.ln_bwd(sv.z1, dh, self.P[a + "layer_norm.weight"], lens, sv.mean1, sv.rstd1,
+                              G[a + "layer_norm.weight"], G[a + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
+                              p_pre=p, seed_pre=_site_seed(sv.site), seed_dev=seed_dev)
+        if dy1 is None:
+            dy1 = dz1
+        self._wgrad(G[a + "fc.weight"], G[a + "fc.bias"], dy1, sv.ctx, S)
+        dctx = self._dgemm(W, a + "fc", dy1, S)
+        dqkv = ops.attn_bwd(sv.qkv, sv.ctx, dctx, sv.lse, lens, B, S, n_head, self.d // n_head)
+        self._wgrad(G[a + "qkv.weight"], G[a + "qkv.bias"], dqkv, sv.x, S)
+        return self._dgemm(W, a + "qkv", dqkv, S, res=dz1)
+
+    def _pred_fwd(self, W, kind, x, lens, B, S, p, seed_dev, site, keep):
+        pre = f"variance_adaptor.{kind}_predictor."
+        cl = pre + "conv_layer."
+        k = self.vp["kernel_size"]
+        sv = _Saved()
+        c1 = self._gemm(W, cl + "conv1d_1", x, S, taps=k, pad=(k - 1) // 2, act=ACT_RELU)
+        n1, m1, r1 = ops.ln_fwd(c1, None, self.P[cl + "layer_norm_1.weight"], self.P[cl + "layer_norm_1.bias"], None, B, S,
+                                p_post=p, seed_post=_site_seed(site), seed_dev=seed_dev)
+        c2 = self._gemm(W, cl + "conv1d_2", n1, S, taps=k, pad=1, act=ACT_RELU)
+        n2, m2, r2 = ops.ln_fwd(c2, None, self.P[cl + "layer_norm_2.weight"], self.P[cl + "layer_norm_2.bias"], None, B, S,
+                                p_post=p, seed_post=_site_seed(site + 1), seed_dev=seed_dev)
+        pred = ops.rowdot_fwd(n2, self.P[pre + "linear_layer.weight"], self.P[pre + "linear_layer.bias"], lens, B, S)
+        if keep:
+            sv.x, sv.c1, sv.m1, sv.r1, sv.n1, sv.c2, sv.m2, sv.r2, sv.n2 = x, c1, m1, r1, n1, c2, m2, r2, n2
+            sv.p, sv.site, sv.lens, sv.S = p, site, lens, S
+        return pred, sv
+
+    def _pred_bwd(self, W, G, kind, sv, dpred, B, seed_dev, dx_acc):
+        """returns dx_acc + d(input) ; dx_acc may be None."""
+        pre = f"variance_adaptor.{kind}_predictor."
+        cl = pre + "conv_layer."
+        k = self.vp["kernel_size"]
+        S, p = sv.S, sv.p
+        dn2 = ops.rowdot_bwd(sv.n2, self.P[pre + "linear_layer.weight"], dpred, sv.lens, G[pre + "linear_layer.weight"],
+                             G[pre + "linear_layer.bias"], B, S)
+        _, dc2 = ops.ln_bwd(sv.c2, dn2, self.P[cl + "layer_norm_2.weight"], None, sv.m2, sv.r2, G[cl + "layer_norm_2.weight"],
+                            G[cl + "layer_norm_2.bias"], B, S, want_d1=False, want_d2=True, p_post=p,
+                            seed_post=_site_seed(sv.site + 1), relu_bwd=True, seed_dev=seed_dev)
+        self._wgrad(G[cl + "conv1d_2.conv.weight"], G[cl + "conv1d_2.conv.bias"], dc2, sv.n1, S, taps=k, pad=1)
+        dn1 = self._dgemm(W, cl + "conv1d_2", dc2, S, taps=k, pad=1)
+        _, dc1 = ops.ln_bwd(sv.c1, dn1, self.P[cl + "layer_norm_1.weight"], None, sv.m1, sv.r1, G[cl + "layer_norm_1.weight"],
+                            G[cl + "layer_norm_1.bias"], B, S, want_d1=False, want_d2=True, p_post=p,
+                            seed_post=_site_seed(sv.site), relu_bwd=True, seed_dev=seed_dev)
+        self._wgrad(G[cl + "conv1d_1.conv.weight"], G[cl + "conv1d_1.conv.bias"], dc1, sv.x, S, taps=k, pad=(k - 1) // 2)
+        return self._dgemm(W, cl + "conv1d_1", dc1, S, taps=k, pad=(k - 1) // 2, res=dx_acc)
+
+    # ------------------------------------------------------------------ whole-model forward
+    def run(self, speakers, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, p_targets, e_targets, d_targets,
+            p_control, e_control, d_control):
+        training = self.m.training
+        need_grad = training and torch.is_grad_enabled()
+        st = _Saved()
+        st.speakers, st.texts, st.src_lens, st.L = speakers, texts.contiguous(), src_lens, max_src_len
+        st.mel_lens, st.max_mel_len = mel_lens, max_mel_len
+        st.p_t, st.e_t, st.d_t = p_targets, e_targets, d_targets
+        st.ctl = (p_control, e_control, d_control)
+        st.training, st.need_grad = training, need_grad
+        if need_grad:
+            params = [p for _, p in self.m._trainable_in_backward_order()]
+            mel, post, p_pred, e_pred, logd = _FS2Function.apply(self, st, *params)
+        else:
+            (mel, post, p_pred, e_pred, logd), _ = self.forward(st)
+        B = texts.shape[0]
+        dev = texts.device
+        src_masks = torch.arange(max_src_len, device=dev).unsqueeze(0) >= src_lens.unsqueeze(1)
+        mel_masks = torch.arange(st.Tdec, device=dev).unsqueeze(0) >= st.mel_lens_out.unsqueeze(1)
+        return (mel, post, p_pred, e_pred, logd, st.d_rounded, src_masks, mel_masks, src_lens, st.mel_lens_out)
+
+    def forward(self, st):
+        m, P, cdt, d = self.m, self.P, self.cdt, self.d
+        training, keep = st.training, st.need_grad
+        W = self.weights(need_dgrad=keep)
+        B, L = st.texts.shape
+        assert L == st.L, "texts.shape[1] must equal max_src_len"
+        sv = _Saved()
+        seed_dev = None
+        drop = training and not getattr(m, "disable_dropout", False)   # test hook == patching F.dropout in the reference
+        if drop:
+            ops.bump_counter(self.seed_counter, 0x632BE59BD9B4E019 & 0x7FFFFFFFFFFFFFFF)
+            seed_dev = self.seed_counter.clone()
+        p_enc = self.tc["encoder_dropout"] if drop else 0.0
+        p_dec = self.tc["decoder_dropout"] if drop else 0.0
+        p_vp = self.vp["dropout"] if drop else 0.0
+        p_pn = 0.5 if drop else 0.0
+        src_lens32 = st.src_lens.to(torch.int32)
+
+        # ---- encoder (transformer/Models.py:73-100)
+        n_head = self.tc["encoder_head"]
+        x = ops.embed_pe_fwd(st.texts, P["encoder.src_word_emb.weight"], self._pe(P["encoder.position_enc"], L), cdt)
+        sv.enc = []
+        for i in range(self.tc["encoder_layer"]):
+            x, s = self._fft_fwd(W, f"encoder.layer_stack.{i}.", x, src_lens32, B, L, n_head, p_enc, seed_dev, 10 + 2 * i, keep)
+            sv.enc.append(s)
+        if m.speaker_emb is not None:
+            ops.add_rowvec(x, P["speaker_emb.weight"], st.speakers, B, L)
+
+        # ---- variance adaptor (model/modules.py:102-158)
+        p_control, e_control, d_control = st.ctl
+        logd, sv.dur = self._pred_fwd(W, "duration", x, src_lens32, B, L, p_vp, seed_dev, 100, keep)
+        pitch_phone = m.pitch_feature_level == "phoneme_level"
+        energy_phone = m.energy_feature_level == "phoneme_level"
+        p_pred = e_pred = None
+        if pitch_phone:
+            p_pred, sv.pitch = self._pred_fwd(W, "pitch", x, src_lens32, B, L, p_vp, seed_dev, 102, keep)
+            if st.p_t is None:
+                p_pred = p_pred * p_control if p_control != 1.0 else p_pred
+            vals = st.p_t if st.p_t is not None else p_pred
+            x, sv.pitch_idx = ops.bucket_embed_add_fwd(x, vals.contiguous().view(-1), 1.0, P["variance_adaptor.pitch_bins"],
+                                                       P["variance_adaptor.pitch_embedding.weight"])
+        if energy_phone:
+            e_pred, sv.energy = self._pred_fwd(W, "energy", x, src_lens32, B, L, p_vp, seed_dev, 104, keep)
+            if st.e_t is None:   # NB reference passes p_control here (model/modules.py:124)
+                e_pred = e_pred * p_control if p_control != 1.0 else e_pred
+            vals = st.e_t if st.e_t is not None else e_pred
+            x, sv.energy_idx = ops.bucket_embed_add_fwd(x, vals.contiguous().view(-1), 1.0, P["variance_adaptor.energy_bins"],
+                                                        P["variance_adaptor.energy_embedding.weight"])
+        # ---- length regulator (model/modules.py:128-137,167-194)
+        if st.d_t is not None:
+            dur = st.d_t.contiguous()
+            st.d_rounded = st.d_t
+            T = st.max_mel_len
+        else:
+            dur = ops.duration_round(logd, d_control)
+            st.d_rounded = dur
+            T = st.max_mel_len
+        if T is None:
+            # inference: output length = longest expanded sequence (host sync, as utils/tools.py:93-94 does)
+            cum, _, mel_len = ops.lr_index(dur, 1)
+            T = max(int(mel_len.max().item()), 1)
+        # decoder truncation (transformer/Models.py:145-162)
+        Tdec = T if ((not training) and T > self.max_seq_len) else min(T, self.max_seq_len)
+        cum, idx, mel_len = ops.lr_index(dur, Tdec)
+        st.mel_lens_out, st.Tdec = mel_len, Tdec
+        dec_lens32 = torch.clamp(mel_len, max=Tdec).to(torch.int32)
+        frame_level = (not pitch_phone) or (not energy_phone)
+        pe_dec = self._pe(P["decoder.position_enc"], Tdec)
+        sv.x_lr_in = None
+        y = ops.lr_gather_fwd(x, idx, None if frame_level else pe_dec, B, L, Tdec)
+        if frame_level:
+            if not pitch_phone:
+                p_pred, sv.pitch = self._pred_fwd(W, "pitch", y, dec_lens32, B, Tdec, p_vp, seed_dev, 102, keep)
+                if st.p_t is None:
+                    p_pred = p_pred * p_control if p_control != 1.0 else p_pred
+                vals = st.p_t[:, :Tdec].contiguous() if st.p_t is not None else p_pred
+                y, sv.pitch_idx = ops.bucket_embed_add_fwd(y, vals.view(-1), 1.0, P["variance_adaptor.pitch_bins"],
+                                                           P["variance_adaptor.pitch_embedding.weight"])
+            if not energy_phone:
+                e_pred, sv.energy = self._pred_fwd(W, "energy", y, dec_lens32, B, Tdec, p_vp, seed_dev, 104, keep)
+                if st.e_t is None:
+                    e_pred = e_pred * p_control if p_control != 1.0 else e_pred
+                vals = st.e_t[:, :Tdec].contiguous() if st.e_t is not None else e_pred
+                y, sv.energy_idx = ops.bucket_embed_add_fwd(y, vals.view(-1), 1.0, P["variance_adaptor.energy_bins"],
+                                                            P["variance_adaptor.energy_embedding.weight"])
+            ops.add_pe(y, pe_dec, B, Tdec)
+
+        # ---- decoder (transformer/Models.py:139-171)
+        n_head = self.tc["decoder_head"]
+        sv.dec = []
+        for i in range(self.tc["decoder_layer"]):
+            y, s = self._fft_fwd(W, f"decoder.layer_stack.{i}.", y, dec_lens32, B, Tdec, n_head, p_dec, seed_dev, 30 + 2 * i, keep)
+            sv.dec.append(s)
+
+        # ---- mel linear + postnet (model/fastspeech2.py:95-97, transformer/Layers.py:129-137)
+        mel = self._gemm(W, "mel_linear", y, Tdec)
+        h = mel
+        sv.pn = []
+        for i in range(5):
+            pre = f"postnet.convolutions.{i}."
+            c = self._gemm(W, pre + "0.conv", h, Tdec, taps=5, pad=2)
+            act = ACT_TANH if i < 4 else ACT_NONE
+            res = mel if i == 4 else None
+            if training:
+                h_out, mean_rstd = ops.bn_train_fwd(c, P[pre + "1.weight"], P[pre + "1.bias"], self.Bf[pre + "1.running_mean"],
+                                                    self.Bf[pre + "1.running_var"], act, p_pn, _site_seed(200 + i), res=res,
+                                                    seed_dev=seed_dev)
+                self.Bf[pre + "1.num_batches_tracked"] += 1
+            else:
+                mean_rstd = torch.cat([self.Bf[pre + "1.running_mean"], torch.rsqrt(self.Bf[pre + "1.running_var"] + 1e-5)])
+                h_out = torch.empty_like(c)
+                ops._lib.call("fs2_bn_apply", c.data_ptr(), mean_rstd.data_ptr(), P[pre + "1.weight"].data_ptr(),
+                              P[pre + "1.bias"].data_ptr(), res.data_ptr() if res is not None else None, h_out.data_ptr(),
+                              c.shape[0], c.shape[1], act, 0.0, 0, None, ops.dt(c), ops._stream())
+            if keep:
+                s = _Saved()
+                s.x, s.c, s.mean_rstd, s.act = h, c, mean_rstd, act
+                sv.pn.append(s)
+            h = h_out
+        post = h
+
+        n_mel = mel.shape[1]
+        mel_o = (ops.cast(mel, torch.float32) if cdt != torch.float32 else mel).view(B, Tdec, n_mel)
+        post_o = (ops.cast(post, torch.float32) if cdt != torch.float32 else post).view(B, Tdec, n_mel)
+        if keep:
+            sv.W, sv.B, sv.L, sv.T = W, B, L, Tdec
+            sv.src_lens32, sv.dec_lens32, sv.cum, sv.seed_dev = src_lens32, dec_lens32, cum, seed_dev
+            sv.dec_out, sv.texts, sv.speakers = y, st.texts, st.speakers
+            sv.pitch_phone, sv.energy_phone = pitch_phone, energy_phone
+            sv.p_pn = p_pn
+        return (mel_o, post_o, p_pred, e_pred, logd), sv
+
+    # ------------------------------------------------------------------ whole-model backward
+    def backward(self, sv, dmel, dpost, dp, de, dlogd):
+        m, P, cdt = self.m, self.P, self.cdt
+        G = self._grads()
+        if any(p.grad is None for p in (P["mel_linear.weight"],)):
+            m._flat_grad.zero_()
+            m.attach_grads()
+        W, B, L, T, seed_dev = sv.W, sv.B, sv.L, sv.T, sv.seed_dev
+        n_mel = P["mel_linear.weight"].shape[0]
+
+        def to_c(t, shape):
+            if t is None:
+                return None
+            t = t.contiguous().view(shape)
+            return ops.cast(t, cdt) if t.dtype != cdt else t
+
+        dmel = to_c(dmel, (B * T, n_mel))
+        dpost = to_c(dpost, (B * T, n_mel))
+        zeros = None
+        if dmel is None or dpost is None:
+            zeros = torch.zeros(B * T, n_mel, device=self.device, dtype=cdt)
+        dmel = dmel if dmel is not None else zeros
+        dpost = dpost if dpost is not None else zeros
+
+        # ---- postnet backward
+        g = dpost
+        for i in reversed(range(5)):
+            pre = f"postnet.convolutions.{i}."
+            s = sv.pn[i]
+            dc, dgam, dbet = ops.bn_bwd(s.c, g, s.mean_rstd, P[pre + "1.weight"], P[pre + "1.bias"], s.act, sv.p_pn,
+                                        _site_seed(200 + i), seed_dev=seed_dev)
+            G[pre + "1.weight"] += dgam
+            G[pre + "1.bias"] += dbet
+            self._wgrad(G[pre + "0.conv.weight"], G[pre + "0.conv.bias"], dc, s.x, T, taps=5, pad=2)
+            g = self._dgemm(W, pre + "0.conv", dc, T, taps=5, pad=2, res=dpost if i == 0 else None)
+        dmel_total = ops.add(g, dmel)
+        # ---- mel linear
+        self._wgrad(G["mel_linear.weight"], G["mel_linear.bias"], dmel_total, sv.dec_out, T)
+        dy = self._dgemm(W, "mel_linear", dmel_total, T)
+        # ---- decoder
+        n_head = self.tc["decoder_head"]
+        for i in reversed(range(self.tc["decoder_layer"])):
+            dy = self._fft_bwd(W, G, f"decoder.layer_stack.{i}.", sv.dec[i], dy, sv.dec_lens32, B, T, n_head, seed_dev)
+        # ---- frame-level variance branches + length regulator
+        dpp = dp.contiguous() if dp is not None else None
+        dee = de.contiguous() if de is not None else None
+        if not sv.energy_phone:
+            ops.bucket_embed_bwd(sv.energy_idx, dy, G["variance_adaptor.energy_embedding.weight"])
+            if dee is not None:
+                dy = self._pred_bwd(W, G, "energy", sv.energy, dee, B, seed_dev, dy)
+        if not sv.pitch_phone:
+            ops.bucket_embed_bwd(sv.pitch_idx, dy, G["variance_adaptor.pitch_embedding.weight"])
+            if dpp is not None:
+                dy = self._pred_bwd(W, G, "pitch", sv.pitch, dpp, B, seed_dev, dy)
+        dx = ops.lr_gather_bwd(dy, sv.cum, B, L, T)
+        # ---- phoneme-level variance branches
+        if sv.energy_phone:
+            ops.bucket_embed_bwd(sv.energy_idx, dx, G["variance_adaptor.energy_embedding.weight"])
+            if dee is not None:
+                dx = self._pred_bwd(W, G, "energy", sv.energy, dee, B, seed_dev, dx)
+        if sv.pitch_phone:
+            ops.bucket_embed_bwd(sv.pitch_idx, dx, G["variance_adaptor.pitch_embedding.weight"])
+            if dpp is not None:
+                dx = self._pred_bwd(W, G, "pitch", sv.pitch, dpp, B, seed_dev, dx)
+        if dlogd is not None:
+            dx = self._pred_bwd(W, G, "duration", sv.dur, dlogd.contiguous(), B, seed_dev, dx)
+        if m.speaker_emb is not None:
+            ops.rowvec_bwd(dx, G["speaker_emb.weight"], sv.speakers, B, L)
+        # ---- encoder
+        n_head = self.tc["encoder_head"]
+        for i in reversed(range(self.tc["encoder_layer"])):
+            dx = self._fft_bwd(W, G, f"encoder.layer_stack.{i}.", sv.enc[i], dx, sv.src_lens32, B, L, n_head, seed_dev)
+        ops.embed_bwd(sv.texts, dx, G["encoder.src_word_emb.weight"], pad_idx=0)
+
+
+class _FS2Function(torch.autograd.Function):
+    """The whole acoustic model as one autograd node (parameters are inputs only so that outputs require grad;
+    their gradients are written directly into the flat gradient buffer by Engine.backward)."""
+
+    @staticmethod
+    def forward(ctx, engine, st, *params):
+        outs, sv = engine.forward(st)
+        ctx.engine, ctx.sv, ctx.n = engine, sv, len(params)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dmel, dpost, dp, de, dlogd):
+        ctx.engine.backward(ctx.sv, dmel, dpost, dp, de, dlogd)
+        return (None, None) + (None,) * ctx.n

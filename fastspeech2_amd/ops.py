@@ -8,7 +8,7 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, ACT_GATE = 0, 1, 2, 3, 4
 
 
 def dt(t_or_dtype):
@@ -106,28 +106,28 @@ def attn_bwd(qkv, ctx, dctx, lse, lens, B, S, H, dk=128):
 
 
 # ------------------------------------------------------------------ layer norm
-def ln_fwd(y, res, gamma, beta, lens, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0):
+def ln_fwd(y, res, gamma, beta, lens, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0, seed_dev=None):
     C = y.shape[-1]
     out = torch.empty_like(y)
     mean = torch.empty(B * S, device=y.device, dtype=torch.float32)
     rstd = torch.empty(B * S, device=y.device, dtype=torch.float32)
     _lib.call("fs2_ln_fwd", _p(y), _p(res), _p(gamma), _p(beta), _p(lens), _p(out), _p(mean), _p(rstd), B, S, C, eps,
-              p_pre, seed_pre, p_post, seed_post, dt(y), _stream())
+              p_pre, seed_pre, p_post, seed_post, _p(seed_dev), dt(y), _stream())
     return out, mean, rstd
 
 
 def ln_bwd(z, dout, gamma, lens, mean, rstd, dgamma, dbeta, B, S, want_d1=True, want_d2=False, d1_add=None, p_pre=0.0,
-           seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False):
+           seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False, seed_dev=None):
     C = z.shape[-1]
     d1 = torch.empty_like(z) if want_d1 else None
     d2 = torch.empty_like(z) if want_d2 else None
     _lib.call("fs2_ln_bwd", _p(z), _p(dout), _p(gamma), _p(lens), _p(mean), _p(rstd), _p(d1_add), _p(d1), _p(d2),
-              _p(dgamma), _p(dbeta), B, S, C, p_pre, seed_pre, p_post, seed_post, int(relu_bwd), dt(z), _stream())
+              _p(dgamma), _p(dbeta), B, S, C, p_pre, seed_pre, p_post, seed_post, _p(seed_dev), int(relu_bwd), dt(z), _stream())
     return d1, d2
 
 
 # ------------------------------------------------------------------ batch norm
-def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e-5, momentum=0.1):
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e-5, momentum=0.1, res=None, seed_dev=None):
     M, C = x.shape
     stats = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
     mean_rstd = torch.empty(2 * C, device=x.device, dtype=torch.float32)
@@ -135,16 +135,17 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e
     _lib.call("fs2_bn_finalize", _p(stats), _p(running_mean), _p(running_var), _p(mean_rstd), M, C, eps, momentum,
               _stream())
     out = torch.empty_like(x)
-    _lib.call("fs2_bn_apply", _p(x), _p(mean_rstd), _p(gamma), _p(beta), _p(out), M, C, act, p, seed, dt(x), _stream())
+    _lib.call("fs2_bn_apply", _p(x), _p(mean_rstd), _p(gamma), _p(beta), _p(res), _p(out), M, C, act, p, seed, _p(seed_dev),
+              dt(x), _stream())
     return out, mean_rstd
 
 
-def bn_bwd(x, dout, mean_rstd, gamma, beta, act, p, seed):
+def bn_bwd(x, dout, mean_rstd, gamma, beta, act, p, seed, seed_dev=None):
     M, C = x.shape
     sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
     _lib.call("fs2_bn_bwd", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(sums), _p(dx), M, C, act, p, seed,
-              dt(x), _stream())
+              _p(seed_dev), dt(x), _stream())
     return dx, sums[C:], sums[:C]  # dx, dgamma, dbeta
 
 
@@ -251,3 +252,19 @@ def sumsq(x, out):
 def adam_step(p, g, m, v, gnorm_sq, max_norm, hyper, b1, b2, eps, wd):
     _lib.call("fs2_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(gnorm_sq), float(max_norm), _p(hyper), b1, b2,
               eps, wd, _stream())
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("fs2_add", _p(a), _p(b), _p(out), a.numel(), dt(a), _stream())
+    return out
+
+
+def add_pe(x, pe, B, S):
+    _lib.call("fs2_add_pe", _p(x), _p(pe), B, S, x.shape[-1], dt(x), _stream())
+    return x
+
+
+def bump_counter(ctr, inc=1):
+    _lib.call("fs2_bump_counter", _p(ctr), inc, _stream())

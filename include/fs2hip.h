@@ -28,7 +28,8 @@ extern "C" {
 typedef struct ihipStream_t* fs2_stream_t; /* == hipStream_t */
 
 enum { FS2_F32 = 0, FS2_BF16 = 1 };
-enum { FS2_ACT_NONE = 0, FS2_ACT_RELU = 1, FS2_ACT_TANH = 2, FS2_ACT_LRELU = 3 };
+enum { FS2_ACT_NONE = 0, FS2_ACT_RELU = 1, FS2_ACT_TANH = 2, FS2_ACT_LRELU = 3,
+       FS2_ACT_GATE = 4 /* Y = (R > 0) ? acc+bias : 0 : ReLU backward fused into the data-gradient GEMM */ };
 
 int fs2_version(void);
 const char* fs2_last_error(void);
@@ -64,22 +65,24 @@ int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float
 /* z = drop_pre(y) + res (written back into y); out = mask(drop_post(LN(z)*gamma+beta)); saves mean/rstd. */
 int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, const int32_t* lens, void* out,
                float* mean, float* rstd, int B, int S, int C, float eps, float p_pre, uint64_t seed_pre, float p_post,
-               uint64_t seed_post, int dtype, fs2_stream_t stream);
+               uint64_t seed_post, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 /* d1 = dz (+ d1_add), d2 = dz * dropmask_pre * (relu_bwd ? z>0 : 1); dgamma/dbeta accumulated atomically. */
 int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
                const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta, int B, int S,
-               int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, int relu_bwd, int dtype,
-               fs2_stream_t stream);
+               int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, const uint64_t* seed_dev,
+               int relu_bwd, int dtype, fs2_stream_t stream);
 
 /* ---- BatchNorm1d (+tanh, +dropout) of PostNet: transformer/Layers.py:129-137 ------------------------ */
 int fs2_bn_stats(const void* x, float* stats /*2C, zeroed*/, int M, int C, int dtype, fs2_stream_t stream);
 int fs2_bn_finalize(const float* stats, float* running_mean, float* running_var, float* mean_rstd /*2C*/, int M, int C,
                     float eps, float momentum, fs2_stream_t stream);
-int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, void* out, int M, int C,
-                 int act, float p, uint64_t seed, int dtype, fs2_stream_t stream);
+/* out = drop(act(BN(x))) + res ; seed_dev (optional, device) is added to every dropout seed so that a replayed
+ * hipGraph draws a fresh mask each step. */
+int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, const void* res, void* out,
+                 int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
                float* sums /*2C zeroed: dbeta|dgamma*/, void* dx, int M, int C, int act, float p, uint64_t seed,
-               int dtype, fs2_stream_t stream);
+               const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 
 /* ---- gathers / index kernels ----------------------------------------------------------------------- */
 /* transformer/Models.py:89-91: out = src_word_emb[tok] + position_enc[t] */
@@ -119,6 +122,10 @@ int fs2_rowdot_bwd(const void* x, const float* w, const float* g, const int32_t*
 /* transformer/Layers.py:25,28 masked_fill(mask, 0) in place */
 int fs2_mask_rows(void* x, const int32_t* lens, int B, int S, int C, int dtype, fs2_stream_t stream);
 int fs2_cast(const void* in, int in_dtype, void* out, int out_dtype, size_t n, fs2_stream_t stream);
+int fs2_add(const void* a, const void* b, void* out, size_t n, int dtype, fs2_stream_t stream);
+/* transformer/Models.py:154-162 (frame-level variance configs): x[b,t,:] += position_enc[t,:] */
+int fs2_add_pe(void* x, const float* pe, int B, int S, int C, int dtype, fs2_stream_t stream);
+int fs2_bump_counter(uint64_t* ctr, uint64_t inc, fs2_stream_t stream);
 
 /* ---- optimiser: train.py:93 clip_grad_norm_ + model/optimizer.py:10-51 Adam ------------------------- */
 int fs2_sumsq(const float* x, size_t n, float* out /*+=*/, fs2_stream_t stream);

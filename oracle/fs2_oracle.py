@@ -1,0 +1,375 @@
+"""CPU oracle for the FastSpeech 2 hot path — TEST INFRASTRUCTURE ONLY.
+
+A functional restatement (plain torch CPU ops on a state_dict, fp32 by default, fp64 on request) of the
+reference's algorithm, each function citing the reference file:line it follows.  It is pinned against the live
+reference by tests/golden/make_golden.py (run in the build container, where /root/reference exists) and the
+committed fixtures under tests/golden/.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this module; the product path (fastspeech2_amd/) never does.
+
+Parity status: acoustic model / loss / optimiser / HiFi-GAN are PINNED by golden vectors generated from the
+reference itself.  The STFT mel filterbank follows librosa==0.7.2 `filters.mel` (Slaney) which is absent from
+/root/reference -> that boundary is "parity unpinned" (see DESIGN.md).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def sinusoid_table(n_position, d_hid):
+    """transformer/Models.py:10-30 — float64 numpy angles, sin on even / cos on odd dims, cast to float32."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    angle = pos / np.power(10000.0, 2.0 * (j // 2) / d_hid)
+    table = np.empty_like(angle)
+    table[:, 0::2] = np.sin(angle[:, 0::2])
+    table[:, 1::2] = np.cos(angle[:, 1::2])
+    return torch.from_numpy(table).float()
+
+
+def mask_from_lengths(lengths, max_len=None):
+    """utils/tools.py:91-99 — True = padding."""
+    if max_len is None:
+        max_len = int(lengths.max().item())
+    ids = torch.arange(0, max_len, device=lengths.device).unsqueeze(0)
+    return ids >= lengths.unsqueeze(1)
+
+
+def _conv1d_rows(x, w, b, padding, dilation=1):
+    """nn.Conv1d applied to a (B, S, C) tensor (the reference transposes around every conv:
+    model/modules.py:291-296, transformer/SubLayers.py:87-89)."""
+    return F.conv1d(x.transpose(1, 2), w, b, padding=padding, dilation=dilation).transpose(1, 2)
+
+
+# ------------------------------------------------------------------------------------------------ FFT block
+def multi_head_attention(sd, pre, x, key_pad_mask, n_head, dropout_p, training):
+    """transformer/SubLayers.py:29-57 + transformer/Modules.py:14-25 (post-LN, key-padding mask, no attn dropout)."""
+    B, S, D = x.shape
+    dk = D // n_head
+    q = F.linear(x, sd[pre + "w_qs.weight"], sd[pre + "w_qs.bias"]).view(B, S, n_head, dk).permute(0, 2, 1, 3)
+    k = F.linear(x, sd[pre + "w_ks.weight"], sd[pre + "w_ks.bias"]).view(B, S, n_head, dk).permute(0, 2, 1, 3)
+    v = F.linear(x, sd[pre + "w_vs.weight"], sd[pre + "w_vs.bias"]).view(B, S, n_head, dk).permute(0, 2, 1, 3)
+    attn = torch.matmul(q, k.transpose(-1, -2)) / (dk ** 0.5)
+    attn = attn.masked_fill(key_pad_mask.view(B, 1, 1, S), float("-inf"))
+    attn = torch.softmax(attn, dim=-1)
+    out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, S, D)
+    out = F.dropout(F.linear(out, sd[pre + "fc.weight"], sd[pre + "fc.bias"]), dropout_p, training)
+    return F.layer_norm(out + x, (D,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5)
+
+
+def positionwise_ffn(sd, pre, x, kernel_size, dropout_p, training):
+    """transformer/SubLayers.py:85-93."""
+    h = F.relu(_conv1d_rows(x, sd[pre + "w_1.weight"], sd[pre + "w_1.bias"], (kernel_size[0] - 1) // 2))
+    h = _conv1d_rows(h, sd[pre + "w_2.weight"], sd[pre + "w_2.bias"], (kernel_size[1] - 1) // 2)
+    h = F.dropout(h, dropout_p, training)
+    D = x.shape[-1]
+    return F.layer_norm(h + x, (D,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5)
+
+
+def fft_block(sd, pre, x, pad_mask, n_head, kernel_size, dropout_p, training):
+    """transformer/Layers.py:21-30 — masked_fill(mask, 0) after each sub-layer."""
+    x = multi_head_attention(sd, pre + "slf_attn.", x, pad_mask, n_head, dropout_p, training)
+    x = x.masked_fill(pad_mask.unsqueeze(-1), 0)
+    x = positionwise_ffn(sd, pre + "pos_ffn.", x, kernel_size, dropout_p, training)
+    return x.masked_fill(pad_mask.unsqueeze(-1), 0)
+
+
+def encoder(sd, cfg, texts, pad_mask, training, dropout):
+    """transformer/Models.py:73-100."""
+    tc = cfg["transformer"]
+    L = texts.shape[1]
+    emb = sd["encoder.src_word_emb.weight"]
+    if (not training) and L > cfg["max_seq_len"]:
+        pe = sinusoid_table(L, tc["encoder_hidden"]).to(emb.dtype)
+    else:
+        pe = sd["encoder.position_enc"][0, :L]
+    x = F.embedding(texts, emb, padding_idx=0) + pe.unsqueeze(0)
+    p = tc["encoder_dropout"] if dropout else 0.0
+    for i in range(tc["encoder_layer"]):
+        x = fft_block(sd, f"encoder.layer_stack.{i}.", x, pad_mask, tc["encoder_head"], tc["conv_kernel_size"], p, training)
+    return x
+
+
+def decoder(sd, cfg, x, pad_mask, training, dropout):
+    """transformer/Models.py:139-171 — truncation to max_seq_len in train (or when it fits)."""
+    tc = cfg["transformer"]
+    T = x.shape[1]
+    if (not training) and T > cfg["max_seq_len"]:
+        x = x + sinusoid_table(T, tc["decoder_hidden"]).to(x.dtype).unsqueeze(0)
+    else:
+        T = min(T, cfg["max_seq_len"])
+        x = x[:, :T] + sd["decoder.position_enc"][0, :T].unsqueeze(0)
+        pad_mask = pad_mask[:, :T]
+    p = tc["decoder_dropout"] if dropout else 0.0
+    for i in range(tc["decoder_layer"]):
+        x = fft_block(sd, f"decoder.layer_stack.{i}.", x, pad_mask, tc["decoder_head"], tc["conv_kernel_size"], p, training)
+    return x, pad_mask
+
+
+# ------------------------------------------------------------------------------------------------ variance adaptor
+def variance_predictor(sd, pre, cfg, x, pad_mask, training, dropout):
+    """model/modules.py:242-250, conv stack :209-240 (second conv has padding=1 regardless of kernel size)."""
+    vc = cfg["variance_predictor"]
+    k = vc["kernel_size"]
+    p = vc["dropout"] if dropout else 0.0
+    C = vc["filter_size"]
+    h = _conv1d_rows(x, sd[pre + "conv_layer.conv1d_1.conv.weight"], sd[pre + "conv_layer.conv1d_1.conv.bias"], (k - 1) // 2)
+    h = F.layer_norm(F.relu(h), (C,), sd[pre + "conv_layer.layer_norm_1.weight"], sd[pre + "conv_layer.layer_norm_1.bias"], 1e-5)
+    h = F.dropout(h, p, training)
+    h = _conv1d_rows(h, sd[pre + "conv_layer.conv1d_2.conv.weight"], sd[pre + "conv_layer.conv1d_2.conv.bias"], 1)
+    h = F.layer_norm(F.relu(h), (C,), sd[pre + "conv_layer.layer_norm_2.weight"], sd[pre + "conv_layer.layer_norm_2.bias"], 1e-5)
+    h = F.dropout(h, p, training)
+    out = F.linear(h, sd[pre + "linear_layer.weight"], sd[pre + "linear_layer.bias"]).squeeze(-1)
+    if pad_mask is not None:
+        out = out.masked_fill(pad_mask, 0.0)
+    return out
+
+
+def length_regulate(x, durations, max_len):
+    """model/modules.py:167-194 + utils/tools.py:299-317: repeat row i max(int(d_i),0) times, pad/crop to max_len,
+    mel_len = un-cropped length."""
+    outs, lens = [], []
+    for xb, db in zip(x, durations):
+        reps = torch.clamp(db.to(torch.float64).trunc().to(torch.int64), min=0)  # int(): truncation toward zero
+        e = torch.repeat_interleave(xb, reps, dim=0)
+        lens.append(e.shape[0])
+        outs.append(e)
+    if max_len is None:
+        max_len = max(lens)
+    padded = []
+    for e in outs:
+        if e.shape[0] >= max_len:
+            padded.append(e[:max_len])
+        else:
+            padded.append(F.pad(e, (0, 0, 0, max_len - e.shape[0])))
+    return torch.stack(padded), torch.tensor(lens, dtype=torch.int64)
+
+
+def variance_adaptor(sd, cfg, pcfg, x, src_mask, mel_mask, max_len, p_target, e_target, d_target, p_control,
+                     e_control, d_control, training, dropout):
+    """model/modules.py:102-158.  NB the energy embedding is called with p_control (modules.py:124,146)."""
+    pitch_level = pcfg["preprocessing"]["pitch"]["feature"]
+    energy_level = pcfg["preprocessing"]["energy"]["feature"]
+    pre = "variance_adaptor."
+
+    def embed(kind, h, target, mask, control):
+        pred = variance_predictor(sd, f"{pre}{kind}_predictor.", cfg, h, mask, training, dropout)
+        bins = sd[f"{pre}{kind}_bins"]
+        if target is not None:
+            idx = torch.bucketize(target, bins)
+        else:
+            pred = pred * control
+            idx = torch.bucketize(pred.detach() if False else pred, bins)
+        return pred, F.embedding(idx, sd[f"{pre}{kind}_embedding.weight"])
+
+    log_d = variance_predictor(sd, pre + "duration_predictor.", cfg, x, src_mask, training, dropout)
+    p_pred = e_pred = None
+    if pitch_level == "phoneme_level":
+        p_pred, emb = embed("pitch", x, p_target, src_mask, p_control)
+        x = x + emb
+    if energy_level == "phoneme_level":
+        e_pred, emb = embed("energy", x, e_target, src_mask, p_control)
+        x = x + emb
+    if d_target is not None:
+        x, mel_len = length_regulate(x, d_target, max_len)
+        d_rounded = d_target
+    else:
+        d_rounded = torch.clamp(torch.round(torch.exp(log_d) - 1) * d_control, min=0)
+        x, mel_len = length_regulate(x, d_rounded, max_len)
+        mel_mask = mask_from_lengths(mel_len)
+    if pitch_level == "frame_level":
+        p_pred, emb = embed("pitch", x, p_target, mel_mask, p_control)
+        x = x + emb
+    if energy_level == "frame_level":
+        e_pred, emb = embed("energy", x, e_target, mel_mask, p_control)
+        x = x + emb
+    return x, p_pred, e_pred, log_d, d_rounded, mel_len, mel_mask
+
+
+# ------------------------------------------------------------------------------------------------ postnet + model
+def postnet(sd, x, training, dropout, bn_buffers=None, n_layers=5):
+    """transformer/Layers.py:129-137 — BatchNorm uses batch statistics over ALL B*T positions in training."""
+    p = 0.5 if dropout else 0.0
+    h = x.transpose(1, 2)
+    for i in range(n_layers):
+        pre = f"postnet.convolutions.{i}."
+        w = sd[pre + "0.conv.weight"]
+        h = F.conv1d(h, w, sd[pre + "0.conv.bias"], padding=(w.shape[2] - 1) // 2)
+        rm, rv = sd[pre + "1.running_mean"], sd[pre + "1.running_var"]
+        if training and bn_buffers is not None:
+            rm, rv = bn_buffers[pre + "1.running_mean"], bn_buffers[pre + "1.running_var"]
+        elif training:
+            rm, rv = rm.clone(), rv.clone()
+        h = F.batch_norm(h, rm, rv, sd[pre + "1.weight"], sd[pre + "1.bias"], training, 0.1, 1e-5)
+        if i < n_layers - 1:
+            h = torch.tanh(h)
+        h = F.dropout(h, p, training)
+    return h.transpose(1, 2)
+
+
+def fastspeech2_forward(sd, cfg, pcfg, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None,
+                        max_mel_len=None, p_targets=None, e_targets=None, d_targets=None, p_control=1.0, e_control=1.0,
+                        d_control=1.0, training=False, dropout=False, bn_buffers=None):
+    """model/fastspeech2.py:43-110.  `dropout=False` with training=True gives the deterministic train-mode path
+    (BatchNorm batch statistics live, dropout neutralised) used for gradient parity."""
+    src_masks = mask_from_lengths(src_lens, max_src_len)
+    mel_masks = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None
+    x = encoder(sd, cfg, texts, src_masks, training, dropout)
+    if cfg["multi_speaker"]:
+        x = x + F.embedding(speakers, sd["speaker_emb.weight"]).unsqueeze(1)
+    x, p_pred, e_pred, log_d, d_rounded, mel_lens, mel_masks = variance_adaptor(
+        sd, cfg, pcfg, x, src_masks, mel_masks, max_mel_len, p_targets, e_targets, d_targets, p_control, e_control,
+        d_control, training, dropout)
+    x, mel_masks = decoder(sd, cfg, x, mel_masks, training, dropout)
+    mel = F.linear(x, sd["mel_linear.weight"], sd["mel_linear.bias"])
+    post = postnet(sd, mel, training, dropout, bn_buffers) + mel
+    return mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, mel_lens
+
+
+def fastspeech2_loss(pcfg, batch_targets, predictions):
+    """model/loss.py:19-92.  batch_targets = (mels, pitches, energies, durations)."""
+    mel_t, p_t, e_t, d_t = batch_targets
+    mel, post, p_pred, e_pred, log_d, _, src_masks, mel_masks, _, _ = predictions
+    src_v, mel_v = ~src_masks, ~mel_masks
+    log_d_t = torch.log(d_t.float() + 1).to(log_d.dtype)
+    mel_t = mel_t[:, : mel_v.shape[1], :]
+    pm = src_v if pcfg["preprocessing"]["pitch"]["feature"] == "phoneme_level" else mel_v
+    em = src_v if pcfg["preprocessing"]["energy"]["feature"] == "phoneme_level" else mel_v
+    pitch_loss = F.mse_loss(p_pred.masked_select(pm), p_t.masked_select(pm))
+    energy_loss = F.mse_loss(e_pred.masked_select(em), e_t.masked_select(em))
+    dur_loss = F.mse_loss(log_d.masked_select(src_v), log_d_t.masked_select(src_v))
+    mv = mel_v.unsqueeze(-1)
+    mel_loss = F.l1_loss(mel.masked_select(mv), mel_t.masked_select(mv))
+    post_loss = F.l1_loss(post.masked_select(mv), mel_t.masked_select(mv))
+    total = mel_loss + post_loss + dur_loss + pitch_loss + energy_loss
+    return total, mel_loss, post_loss, pitch_loss, energy_loss, dur_loss
+
+
+def lr_at_step(step, d_model, warmup, anneal_steps, anneal_rate):
+    """model/optimizer.py:33-51 (step is the already-incremented current_step)."""
+    lr = min(step ** -0.5, warmup ** -1.5 * step)
+    for s in anneal_steps:
+        if step > s:
+            lr *= anneal_rate
+    return d_model ** -0.5 * lr
+
+
+# ------------------------------------------------------------------------------------------------ HiFi-GAN
+def hifigan_forward(sd, h, mel):
+    """hifigan/models.py:149-165 with weight norm already removed (plain `weight` keys).
+    mel: (B, 80, T) -> (B, 1, 256 T).  Last leaky_relu uses the DEFAULT slope 0.01 (models.py:161)."""
+    x = F.conv1d(mel, sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
+    nk = len(h["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, 0.1)
+        x = F.conv_transpose1d(x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+        xs = None
+        for j, (rk, rd) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+            pre = f"resblocks.{i * nk + j}."
+            y = x
+            for m, d in enumerate(rd):
+                t = F.leaky_relu(y, 0.1)
+                t = F.conv1d(t, sd[f"{pre}convs1.{m}.weight"], sd[f"{pre}convs1.{m}.bias"], dilation=d, padding=(rk * d - d) // 2)
+                t = F.leaky_relu(t, 0.1)
+                t = F.conv1d(t, sd[f"{pre}convs2.{m}.weight"], sd[f"{pre}convs2.{m}.bias"], padding=(rk - 1) // 2)
+                y = t + y
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = F.leaky_relu(x)
+    x = F.conv1d(x, sd["conv_post.weight"], sd["conv_post.bias"], padding=3)
+    return torch.tanh(x)
+
+
+def remove_weight_norm_sd(sd):
+    """weight_g / weight_v -> weight = g * v / ||v|| (norm over all dims but 0), as torch.nn.utils.weight_norm."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("weight_v"):
+            g = sd[k[:-1] + "g"]
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+            out[k[:-2]] = v * (g / norm)
+        elif k.endswith("weight_g"):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+def pcm16(wav, max_wav_value=32768.0):
+    """utils/model.py:82-85 — numpy astype('int16') after scaling: truncation toward zero, no clipping."""
+    return (wav.detach().cpu().numpy() * max_wav_value).astype("int16")
+
+
+# ------------------------------------------------------------------------------------------------ STFT / mel
+def slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    """librosa==0.7.2 filters.mel(sr, n_fft, n_mels, fmin, fmax) (htk=False, norm=1 -> Slaney area norm).
+    Third-party algorithm restated from its published definition (librosa is not vendored in the reference;
+    pinned at requirements.txt:3, called at audio/stft.py:145-147)."""
+    if fmax is None:
+        fmax = sr / 2.0
+
+    def hz_to_mel(f):
+        f = np.asanyarray(f, dtype=np.float64)
+        f_sp = 200.0 / 3
+        mels = f / f_sp
+        min_log_hz = 1000.0
+        min_log_mel = min_log_hz / f_sp
+        logstep = np.log(6.4) / 27.0
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+    def mel_to_hz(m):
+        m = np.asanyarray(m, dtype=np.float64)
+        f_sp = 200.0 / 3
+        freqs = f_sp * m
+        min_log_hz = 1000.0
+        min_log_mel = min_log_hz / f_sp
+        logstep = np.log(6.4) / 27.0
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+
+    n_freq = 1 + n_fft // 2
+    fftfreqs = np.linspace(0, sr / 2.0, n_freq)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, n_freq))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2 : n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, None]
+    return weights.astype(np.float32)
+
+
+def stft_basis(filter_length, win_length):
+    """audio/stft.py:26-50: [Re; Im] of FFT(I)[:cutoff] times a periodic hann window, float32."""
+    from scipy.signal import get_window
+
+    fb = np.fft.fft(np.eye(filter_length))
+    cutoff = filter_length // 2 + 1
+    fb = np.vstack([np.real(fb[:cutoff]), np.imag(fb[:cutoff])])
+    win = get_window("hann", win_length, fftbins=True)
+    if win_length < filter_length:  # librosa.util.pad_center
+        lpad = (filter_length - win_length) // 2
+        win = np.pad(win, (lpad, filter_length - win_length - lpad))
+    basis = torch.FloatTensor(fb) * torch.from_numpy(win).float()
+    return basis  # (2*cutoff, filter_length)
+
+
+def mel_spectrogram(y, filter_length=1024, hop_length=256, win_length=1024, n_mel=80, sr=22050, fmin=0, fmax=8000,
+                    mel_basis=None):
+    """audio/stft.py:159-178 (+ :52-81 transform, audio_processing.py:85-91): y (B, N) in [-1,1] ->
+    (mel (B, n_mel, frames), energy (B, frames))."""
+    assert y.min() >= -1 and y.max() <= 1
+    basis = stft_basis(filter_length, win_length)
+    x = F.pad(y.unsqueeze(1), (filter_length // 2, filter_length // 2), mode="reflect")
+    ft = F.conv1d(x, basis.unsqueeze(1), stride=hop_length)
+    cutoff = filter_length // 2 + 1
+    mag = torch.sqrt(ft[:, :cutoff] ** 2 + ft[:, cutoff:] ** 2)
+    if mel_basis is None:
+        mel_basis = torch.from_numpy(slaney_mel_filterbank(sr, filter_length, n_mel, fmin, fmax))
+    mel = torch.log(torch.clamp(torch.matmul(mel_basis, mag), min=1e-5))
+    energy = torch.norm(mag, dim=1)
+    return mel, energy
