@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py — mel-frames/s of the FastSpeech 2 TRAIN step on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+A "step" = forward + FastSpeech2Loss + backward + (RCCL gradient all-reduce) + global-norm clip + Adam over one
+synthetic LJSpeech-shaped batch per GPU (config 2 of BASELINE.json: 4+4 FFT layers, d=256, 2 heads, 80-bin mel,
+batch 48 per GPU, ~128 phonemes -> ~900 frames, bf16 compute with fp32 master weights), inputs resident in HBM.
+value = sum of valid mel frames over all ranks and K steps / max-over-ranks wall time.
+
+The same JSON line carries
+  roofline     — the dominant kernel (conv_gemm MFMA contraction): algorithmic FLOPs of its launches / their HIP-event
+                 durations, measured in an instrumented replay of the same step right after the timed region;
+  cpu_baseline — the CPU oracle (a port of the reference algorithm, oracle/fs2_oracle.py) timed on this host's
+                 cores on a bounded sample (B=4, 2 steps) of the same workload.  Reported, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+TRAIN_FLOP_PER_FRAME = 117.5e6                         # 3 x 39.17 MFLOP fwd (4+4, phoneme-level)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=48)
+    ap.add_argument("--phonemes", type=int, default=128)
+    ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (1 GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build(args, device, rank, world):
+    from tests.golden import configs
+    from oracle.weights import synthetic_batch
+    from fastspeech2_amd.model import FastSpeech2, FastSpeech2Loss, ScheduledOptim
+    from fastspeech2_amd import ddp
+
+    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
+    torch.manual_seed(1234)
+    model = FastSpeech2(pcfg, mcfg, compute_dtype=args.dtype).to(device)
+    model.train()
+    model._ensure_flat(device)
+    b = synthetic_batch(1234 + rank, args.batch, args.phonemes, dur_lo=4, dur_hi=10, min_len_frac=0.75)
+    b = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    loss_fn = FastSpeech2Loss(pcfg, mcfg, count_reduce=ddp.global_counts if world > 1 else None)
+    opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
+    opt._ensure()
+    return model, loss_fn, opt, b, pcfg, mcfg
+
+
+def make_step(model, loss_fn, opt, b, exchange):
+    batch12 = (None, None, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"],
+               b["max_mel_len"], b["pitches"], b["energies"], b["durations"])
+
+    def fwd_bwd():
+        out = model(*batch12[2:])
+        losses = loss_fn(batch12, out)
+        losses[0].backward()
+        return losses[0].detach()
+
+    def step():
+        loss = fwd_bwd()
+        if exchange is not None:
+            exchange.finish()
+        opt.step_and_update_lr()
+        opt.zero_grad()
+        return loss
+
+    return step, fwd_bwd
+
+
+def cpu_baseline(args):
+    """CPU oracle (port of the reference algorithm) on a bounded sample: B=4, same L/T, fwd+loss+bwd+clip+Adam."""
+    from tests.golden import configs
+    from oracle import fs2_oracle as O
+    from oracle.weights import synthetic_batch
+    from fastspeech2_amd.model import FastSpeech2
+
+    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
+    torch.manual_seed(1234)
+    sd = {k: v.clone() for k, v in FastSpeech2(pcfg, mcfg).state_dict().items()}
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and not any(s in k for s in ("position_enc", "_bins", "running_")):
+            v.requires_grad_(True)
+            params.append(v)
+    opt = torch.optim.Adam(params, betas=(0.9, 0.98), eps=1e-9)
+    b = synthetic_batch(1234, 4, args.phonemes, dur_lo=4, dur_hi=10, min_len_frac=0.75)
+    bn = {k: v for k, v in sd.items() if "running_" in k}
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        out = O.fastspeech2_forward(sd, mcfg, pcfg, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"],
+                                    b["mel_lens"], b["max_mel_len"], b["pitches"], b["energies"], b["durations"],
+                                    training=True, dropout=True, bn_buffers=bn)
+        loss = O.fastspeech2_loss(pcfg, (b["mels"], b["pitches"], b["energies"], b["durations"]), out)[0]
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    frames = int(b["mel_lens"].sum())
+    return {"value": round(frames / t, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle train step, B=4, L={args.phonemes}, T={b['max_mel_len']}, best of 2 timed steps ({t:.2f} s/step), "
+                      f"host cpu_count={os.cpu_count()}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from fastspeech2_amd import ddp, ops
+    model, loss_fn, opt, b, pcfg, mcfg = build(args, device, rank, world)
+    exchange = None
+    if world > 1:
+        exchange = ddp.GradExchange(model.flat_gradients(), world)
+        model._engine.grad_hook = exchange.ready
+        dist.broadcast(model.flat_parameters(), 0)
+    step, fwd_bwd = make_step(model, loss_fn, opt, b, exchange)
+
+    use_graph = bool(args.graph) and world == 1
+    graph = None
+    for _ in range(max(args.warmup, 3) if use_graph else args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            # capture forward + loss + backward + clip/Adam; lr / bias corrections are read from device memory
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                static_loss = fwd_bwd()
+                opt.apply_update()
+                model.flat_gradients().zero_()
+            torch.cuda.synchronize()
+        except Exception as e:  # capture is an optimisation, never a change of what is computed
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            opt.current_step += 1
+            opt._adam_step += 1
+            lr = opt.init_lr * opt._get_lr_scale()
+            b1, b2 = opt.betas
+            opt._hyper.copy_(torch.tensor([lr, 1 - b1 ** opt._adam_step, 1 - b2 ** opt._adam_step, 0.0]))
+            graph.replay()
+        else:
+            step()
+
+    for _ in range(2):
+        run_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    frames = b["mel_lens"].sum().to(torch.float64)
+    padded = torch.tensor([float(args.batch * b["max_mel_len"])], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(frames)
+        dist.all_reduce(padded)
+    dt = tmax.item()
+    value = frames.item() * args.steps / dt
+    final_loss = float((static_loss if graph is not None else loss).item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented eager replay of the same step: HIP events around every conv_gemm launch on its stream
+        ops.PROFILE = {}
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        rec = prof.get("conv_gemm", [])
+        ms = sum(e0.elapsed_time(e1) for (_, e0, e1) in rec)
+        fl = sum(f for (f, _, _) in rec)
+        if ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s>" % args.dtype, "achieved": round(ach, 1),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "launches_per_step": len(rec) // 3, "kernel_ms_per_step": round(ms / 3, 3),
+                        "step_frac_of_peak": round(value / world * TRAIN_FLOP_PER_FRAME / (peak * 1e12), 4)}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        line = {
+            "metric": "mel-frames/sec (train, 80-bin)", "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: LJSpeech train, 4+4 FFT layers d=256 2 heads, 80-bin mel, "
+                                   f"batch={args.batch}/GPU, L={args.phonemes} phonemes, T={b['max_mel_len']} frames, "
+                                   "fwd+loss+bwd+clip+Adam, dropout on, fp32 master weights",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                       "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

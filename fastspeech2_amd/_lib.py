@@ -7,6 +7,9 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- must come first: torch bundles its own libamdhip64.so.7; loading ours afterwards makes
+#                          libfs2hip.so bind to that SAME HIP runtime (two runtimes in one process cannot share streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfs2hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fs2hip.h")

@@ -1,0 +1,96 @@
+"""Data-parallel gradient exchange over RCCL/xGMI (replaces the reference's nn.DataParallel, train.py:42).
+
+One process per GPU.  Every trainable gradient lives in ONE flat fp32 buffer laid out in backward-completion
+order (fastspeech2_amd.model.FastSpeech2._trainable_in_backward_order), so the exchange is a few large
+contiguous all-reduces instead of 183 small ones: xGMI is point-to-point (7 links x ~153 GB/s per GPU) and
+ring all-reduce is per-link bound, so big buckets amortise the per-collective latency best.  Buckets are
+launched on a side stream as soon as the engine reports that a prefix of the flat buffer is final, which
+overlaps the exchange with the rest of backward (the decoder's gradients travel while the encoder's are still
+being computed).
+
+The reference computes its loss over the gathered global batch (train.py:82-86).  `global_counts` provides
+the all-reduced valid-position counts so each rank can normalise its loss terms by (global count / world):
+averaging gradients over ranks then reproduces the global-batch mean exactly.
+
+Device-agnostic on purpose: the same code runs with the `gloo` backend on CPU tensors in the unit tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradExchange:
+    def __init__(self, flat_grad, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True):
+        self.flat = flat_grad
+        self.group = group
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.n = flat_grad.numel()
+        self.cuda = flat_grad.is_cuda
+        self.overlap = overlap and self.cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.reset()
+
+    def reset(self):
+        self.sent = 0          # prefix [0, sent) already handed to the collective
+        self.handles = []
+
+    def _launch(self, lo, hi):
+        view = self.flat[lo:hi]
+        if self.cuda and self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                view.div_(self.world)
+                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            view.div_(self.world)
+            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append(h)
+
+    def ready(self, end):
+        """Engine hook: gradients in flat[0:end) are final.  Launch every full bucket inside that prefix."""
+        if self.world == 1:
+            return
+        end = min(end, self.n)
+        while end - self.sent >= self.bucket_elems:
+            self._launch(self.sent, self.sent + self.bucket_elems)
+            self.sent += self.bucket_elems
+
+    def finish(self):
+        """Flush the tail bucket and make the compute stream wait for all collectives."""
+        if self.world == 1:
+            self.reset()
+            return
+        if self.sent < self.n:
+            self._launch(self.sent, self.n)
+            self.sent = self.n
+        for h in self.handles:
+            h.wait()
+        if self.cuda and self.overlap:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.reset()
+
+
+def global_counts(counts, group=None):
+    """all-reduce (sum) a small tensor of valid-position counts; returns counts / world (so that a local loss
+    normalised by it, averaged over ranks, equals the global-batch mean)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return counts
+    c = counts.clone().float()
+    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+    return c / dist.get_world_size(group)
+
+
+def shard_by_length(lengths, world_size, rank, batch_size):
+    """Length-bucketed sharding (replaces dataset.py:127-146's sort-within-4x-batch for the multi-GPU case):
+    sort the global index list by length, cut it into groups of world_size*batch_size, and deal each group's
+    consecutive batch_size-chunks to the ranks so that every rank gets similar lengths in the same step.
+    Returns the list of index lists (one per step) for `rank`."""
+    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    per_step = world_size * batch_size
+    steps = []
+    for s in range(0, len(order) - per_step + 1, per_step):
+        grp = order[s:s + per_step]
+        steps.append(grp[rank * batch_size:(rank + 1) * batch_size])
+    return steps

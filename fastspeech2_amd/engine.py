@@ -43,6 +43,7 @@ class Engine:
         self.P = dict(model.named_parameters())
         self.Bf = dict(model.named_buffers())
         self.G = None   # name -> grad view (built lazily)
+        self.grad_hook = None   # callable(end_offset): flat_grad[0:end_offset) is final (see ddp.GradExchange.ready)
 
     # ------------------------------------------------------------------ weights
     def _flat_view(self, first_name, numel, shape, grad=False):
@@ -118,6 +119,10 @@ class Engine:
             from .model import sinusoid_table
             self._pe_cache[key] = sinusoid_table(n, tab.shape[1]).to(self.device)
         return self._pe_cache[key]
+
+    def _ready(self, next_name):
+        if self.grad_hook is not None:
+            self.grad_hook(self.m._flat_offsets[next_name] if next_name else self.m._flat.numel())
 
     # ------------------------------------------------------------------ building blocks
     def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
@@ -408,8 +413,11 @@ class Engine:
         dy = self._dgemm(W, "mel_linear", dmel_total, T)
         # ---- decoder
         n_head = self.tc["decoder_head"]
+        va_first = "variance_adaptor.energy_predictor.linear_layer.weight"
         for i in reversed(range(self.tc["decoder_layer"])):
+            self._ready(f"decoder.layer_stack.{i}.pos_ffn.layer_norm.weight")
             dy = self._fft_bwd(W, G, f"decoder.layer_stack.{i}.", sv.dec[i], dy, sv.dec_lens32, B, T, n_head, seed_dev)
+        self._ready(va_first)
         # ---- frame-level variance branches + length regulator
         dpp = dp.contiguous() if dp is not None else None
         dee = de.contiguous() if de is not None else None
@@ -438,8 +446,11 @@ class Engine:
         # ---- encoder
         n_head = self.tc["encoder_head"]
         for i in reversed(range(self.tc["encoder_layer"])):
+            self._ready(f"encoder.layer_stack.{i}.pos_ffn.layer_norm.weight")
             dx = self._fft_bwd(W, G, f"encoder.layer_stack.{i}.", sv.enc[i], dx, sv.src_lens32, B, L, n_head, seed_dev)
+        self._ready("encoder.src_word_emb.weight")
         ops.embed_bwd(sv.texts, dx, G["encoder.src_word_emb.weight"], pad_idx=0)
+        self._ready(None)
 
 
 class _FS2Function(torch.autograd.Function):

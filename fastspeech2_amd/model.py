@@ -313,10 +313,13 @@ class FastSpeech2Loss(nn.Module):
     """reference model/loss.py:5-92.  Masked means over valid positions; thin elementwise work left to torch
     device ops (SURVEY §8(f) rank 2 lists the fused-loss kernel as a "next" row)."""
 
-    def __init__(self, preprocess_config, model_config):
+    def __init__(self, preprocess_config, model_config, count_reduce=None):
         super().__init__()
         self.pitch_feature_level = preprocess_config["preprocessing"]["pitch"]["feature"]
         self.energy_feature_level = preprocess_config["preprocessing"]["energy"]["feature"]
+        # data-parallel runs pass ddp.global_counts so that every rank normalises by (global valid count / world):
+        # the rank-averaged gradient then equals the reference's global-batch mean (train.py:82-86)
+        self.count_reduce = count_reduce
 
     def forward(self, inputs, predictions):
         mel_targets, _, _, pitch_targets, energy_targets, duration_targets = inputs[6:]
@@ -324,14 +327,16 @@ class FastSpeech2Loss(nn.Module):
         src_v, mel_v = ~src_masks, ~mel_masks
         logd_t = torch.log(duration_targets.float() + 1)
         mel_targets = mel_targets[:, : mel_v.shape[1], :]
+        counts = torch.stack([src_v.sum(), mel_v.sum()]).float()
+        if self.count_reduce is not None:
+            counts = self.count_reduce(counts)
+        n_of = {id(src_v): counts[0], id(mel_v): counts[1]}
 
         def masked_mse(pred, tgt, valid):
-            n = valid.sum()
-            return (((pred - tgt) ** 2) * valid).sum() / n
+            return (((pred - tgt) ** 2) * valid).sum() / n_of[id(valid)]
 
         def masked_l1(pred, tgt, valid):
-            n = valid.sum() * pred.shape[-1]
-            return ((pred - tgt).abs() * valid.unsqueeze(-1)).sum() / n
+            return ((pred - tgt).abs() * valid.unsqueeze(-1)).sum() / (n_of[id(valid)] * pred.shape[-1])
 
         pm = src_v if self.pitch_feature_level == "phoneme_level" else mel_v
         em = src_v if self.energy_feature_level == "phoneme_level" else mel_v

@@ -10,6 +10,10 @@ from . import _lib
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, ACT_GATE = 0, 1, 2, 3, 4
 
+# bench.py instrumentation: when a dict, every conv_gemm launch is bracketed by HIP events on its own stream and
+# recorded as (algorithmic FLOPs, start, end).  None in normal operation (zero overhead).
+PROFILE = None
+
 
 def dt(t_or_dtype):
     d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
@@ -71,8 +75,14 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     if ldy is None:
         ldy = out.stride(0) if out.dim() == 2 else N
     ldr = res.stride(0) if res is not None else 0
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("fs2_conv_gemm", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), M, N, Cin, S,
               taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1))
     return out
 
 
