@@ -138,6 +138,343 @@ __global__ void __launch_bounds__(256, 1) attn_fwd_kernel(const T* __restrict__ 
     }
 }
 
+
+// ====================================================================================================
+// bf16 path: v_mfma_f32_32x32x16_bf16 (2.5 PF roof), same register-resident-P structure as the f32 kernels.
+// Tiles are [rows][128] bf16 (256-B rows) with ONE swizzle that serves both access patterns:
+//   16-B chunk c of row r lives at chunk c ^ S(r),  S(r) = ((r&3)<<2) | ((r>>2)&3)
+//   * ds_read_b128 of one chunk by 16 distinct rows (K-contiguous operand)      -> 16 distinct slots
+//   * ds_read_b64_tr_b16 of 4 consecutive rows x 64 B (row-major operand, transposing) -> 4 distinct bank quarters
+// k-slot convention of every MFMA here: lane half h = lane>>5, element e = 0..7.
+//   K-contiguous operands: d = 16*s + 8*h + e.
+//   row-indexed operands (P / dS as A, V / dO / Q / K as B): row = 16*u + 4*h + (e&3) + 8*(e>>2)  — exactly the rows
+//   a lane owns in the 32x32 C layout, so probabilities feed the next MFMA straight from registers.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s4p;
+
+__device__ __forceinline__ int swzb(int row, int c16) { return row * 256 + ((c16 ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+template <int NT, int ROWS>
+__device__ __forceinline__ void stage_tile_bf16(unsigned char* lds, const bf16_t* __restrict__ base, long ld, int row0,
+                                                int nrows_valid, int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 16 / NT; ++i) {
+        int idx = tid + NT * i;
+        int r = idx >> 4, c = idx & 15;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < nrows_valid) v = *reinterpret_cast<const uint4*>(base + (size_t)(row0 + r) * ld + c * 8);
+        *reinterpret_cast<uint4*>(lds + swzb(r, c)) = v;
+    }
+}
+// K-contiguous fragment: row `row`, d-slots 16*s + 8*h .. +7
+__device__ __forceinline__ bf16x8 frag_k(const unsigned char* lds, int row, int s, int h) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + swzb(row, 2 * s + h)));
+}
+// transposed fragment: rows rowbase + 4h + {0..3, 8..11}, column col (= 32*nb + lane&31)
+__device__ __forceinline__ bf16x8 frag_t(const unsigned char* lds, int rowbase, int nb, int lane) {
+    int li = lane & 15, g = lane >> 4, h = g >> 1;
+    int row = rowbase + 4 * h + (li >> 2);
+    int col = nb * 32 + 16 * (g & 1) + 4 * (li & 3);       // 8-byte piece inside 16-B chunk col>>3
+    int off0 = swzb(row, col >> 3) + ((col & 7) << 1);
+    int off1 = swzb(row + 8, col >> 3) + ((col & 7) << 1);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(lds + off0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(lds + off1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ bf16x8 pack8(const float* p) {
+    s16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (short)f32_to_bf16(p[i]);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// load this lane's K-contiguous register fragments of one row (8 steps x 8 bf16), optionally scaled
+__device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* row, int h, bool ok) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = *reinterpret_cast<const uint4*>(row + 16 * s + 8 * h);
+        f[s] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
+                                                               long ldo, float* __restrict__ lse,
+                                                               const int32_t* __restrict__ lens, int S, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(lens[b], S) : S;
+    const int q0 = qt * 128;
+    const size_t rowbase = (size_t)b * S;
+    bf16_t* out = ctx + rowbase * ldo + h * DK;
+    float* lse_o = lse + ((size_t)b * H + h) * S;
+    if (q0 >= len) {
+        for (int i = tid; i < 128 * 32; i += 256) {
+            int r = i >> 5, c = (i & 31) * 4;
+            if (q0 + r < S) st4<bf16_t>(out + (size_t)(q0 + r) * ldo + c, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        if (tid < 128 && q0 + tid < S) lse_o[q0 + tid] = 0.f;
+        return;
+    }
+    const bf16_t* Q = qkv + rowbase * ld + h * DK;
+    const bf16_t* K = qkv + rowbase * ld + (size_t)H * DK + h * DK;
+    const bf16_t* V = qkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    const int myq = q0 + w * 32 + fl;
+    bf16x8 qf[8];
+    load_row_frags(qf, Q + (size_t)min(myq, S - 1) * ld, h2, myq < S);
+    f32x16 o[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        __syncthreads();
+        stage_tile_bf16<256, 64>(sK, K, ld, k0, min(64, S - k0), tid);
+        stage_tile_bf16<256, 64>(sV, V, ld, k0, min(64, S - k0), tid);
+        __syncthreads();
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sK, kb * 32 + fl, st, h2), qf[st], s[kb], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[kb][r] * scale;
+                if (k0 + kb * 32 + crow(r, h2) >= len) v = -INFINITY;
+                s[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mn = fmaxf(m, mx);
+        float alpha = __expf(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[kb][r] = __expf(s[kb][r] - mn); rs += s[kb][r]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float ar = __shfl(alpha, crow(r, h2), 64);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = s[kb][8 * u + e];
+                bf16x8 pa = pack8(pv);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t(sV, kb * 32 + 16 * u, nb, lane), o[nb], 0, 0, 0);
+            }
+    }
+    float linv = l > 0.f ? 1.f / l : 0.f;
+    if (h2 == 0 && myq < S) lse_o[myq] = (l > 0.f) ? m + __logf(l) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float li = __shfl(linv, crow(r, h2), 64);
+        int q = q0 + w * 32 + crow(r, h2);
+        if (q < S) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) out[(size_t)q * ldo + nb * 32 + fl] = f32_to_bf16(o[nb][r] * li);
+        }
+    }
+}
+
+// dK, dV: one wave owns 32 keys (K, V fragments in registers); the block streams 64-query tiles of Q / dO.
+__global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                                   const bf16_t* __restrict__ dctx, long ldo,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,
+                                                                   int S, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char sQ[64 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sdO[64 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(lens[b], S) : S;
+    const size_t rowbase = (size_t)b * S;
+    const int kbase = kt * 128 + w * 32;
+    bf16_t* dK = dqkv + rowbase * ld + (size_t)H * DK + h * DK;
+    bf16_t* dV = dqkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    if (kt * 128 >= len) {
+        for (int i = tid; i < 128 * 32; i += 256) {
+            int r = i >> 5, c = (i & 31) * 4;
+            if (kt * 128 + r < S) {
+                st4<bf16_t>(dK + (size_t)(kt * 128 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+                st4<bf16_t>(dV + (size_t)(kt * 128 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+        return;
+    }
+    const bf16_t* Q = qkv + rowbase * ld + h * DK;
+    const bf16_t* K = qkv + rowbase * ld + (size_t)H * DK + h * DK;
+    const bf16_t* V = qkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    const bf16_t* dO = dctx + rowbase * ldo + h * DK;
+    const float* lse_b = lse + ((size_t)b * H + h) * S;
+    const float* del_b = delta + ((size_t)b * H + h) * S;
+    const int mykey = kbase + fl;
+    const bool key_ok = mykey < len;
+    bf16x8 kf[8], vf[8];
+    load_row_frags(kf, K + (size_t)min(mykey, S - 1) * ld, h2, mykey < S);
+    load_row_frags(vf, V + (size_t)min(mykey, S - 1) * ld, h2, mykey < S);
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[nb][r] = 0.f; dv[nb][r] = 0.f; }
+
+    for (int q0 = 0; q0 < len; q0 += 64) {
+        __syncthreads();
+        stage_tile_bf16<256, 64>(sQ, Q, ld, q0, min(64, S - q0), tid);
+        stage_tile_bf16<256, 64>(sdO, dO, ldo, q0, min(64, S - q0), tid);
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (q0 + qb * 32 >= len) break;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sQ, qb * 32 + fl, st, h2), kf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sdO, qb * 32 + fl, st, h2), vf[st], dp, 0, 0, 0);
+            }
+            float pv[16], dsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int q = q0 + qb * 32 + crow(r, h2);
+                float p = 0.f, ds = 0.f;
+                if (key_ok && q < len) {
+                    p = __expf(s[r] * scale - lse_b[q]);
+                    ds = p * (dp[r] - del_b[q]) * scale;
+                }
+                pv[r] = p; dsv[r] = ds;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 pa = pack8(pv + 8 * u), da = pack8(dsv + 8 * u);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t(sdO, qb * 32 + 16 * u, nb, lane), dv[nb], 0, 0, 0);
+                    dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_t(sQ, qb * 32 + 16 * u, nb, lane), dk[nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int key = kbase + crow(r, h2);
+        if (key < S) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                dK[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dk[nb][r]);
+                dV[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dv[nb][r]);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                                  const bf16_t* __restrict__ dctx, long ldo,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,
+                                                                  int S, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(lens[b], S) : S;
+    const int q0 = qt * 128;
+    const size_t rowbase = (size_t)b * S;
+    bf16_t* dQ = dqkv + rowbase * ld + h * DK;
+    if (q0 >= len) {
+        for (int i = tid; i < 128 * 32; i += 256) {
+            int r = i >> 5, c = (i & 31) * 4;
+            if (q0 + r < S) st4<bf16_t>(dQ + (size_t)(q0 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        return;
+    }
+    const bf16_t* Q = qkv + rowbase * ld + h * DK;
+    const bf16_t* K = qkv + rowbase * ld + (size_t)H * DK + h * DK;
+    const bf16_t* V = qkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    const bf16_t* dO = dctx + rowbase * ldo + h * DK;
+    const int myq = q0 + w * 32 + fl;
+    const bool q_ok = myq < len;
+    float my_lse = 0.f, my_del = 0.f;
+    if (myq < S) { my_lse = lse[((size_t)b * H + h) * S + myq]; my_del = delta[((size_t)b * H + h) * S + myq]; }
+    bf16x8 qf[8], df[8];
+    load_row_frags(qf, Q + (size_t)min(myq, S - 1) * ld, h2, myq < S);
+    load_row_frags(df, dO + (size_t)min(myq, S - 1) * ldo, h2, myq < S);
+    f32x16 dq[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[nb][r] = 0.f;
+
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        __syncthreads();
+        stage_tile_bf16<256, 64>(sK, K, ld, k0, min(64, S - k0), tid);
+        stage_tile_bf16<256, 64>(sV, V, ld, k0, min(64, S - k0), tid);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (k0 + kb * 32 >= len) break;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sK, kb * 32 + fl, st, h2), qf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sV, kb * 32 + fl, st, h2), df[st], dp, 0, 0, 0);
+            }
+            float dsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int key = k0 + kb * 32 + crow(r, h2);
+                float ds = 0.f;
+                if (q_ok && key < len) {
+                    float p = __expf(s[r] * scale - my_lse);
+                    ds = p * (dp[r] - my_del) * scale;
+                }
+                dsv[r] = ds;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 da = pack8(dsv + 8 * u);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_t(sK, kb * 32 + 16 * u, nb, lane), dq[nb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int q = q0 + w * 32 + crow(r, h2);
+        if (q < S) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) dQ[(size_t)q * ld + nb * 32 + fl] = f32_to_bf16(dq[nb][r]);
+        }
+    }
+}
+
 extern "C" int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_t* lens, int B, int S, int H, int dk,
                             float scale, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(qkv && ctx && lse, "attn_fwd: null pointer");
@@ -147,7 +484,7 @@ extern "C" int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_
     dim3 grid(fs2_cdiv(S, 128), H, B);
     long ld = 3L * H * DK, ldo = (long)H * DK;
     if (dtype == FS2_F32) attn_fwd_kernel<float><<<grid, 256, 0, stream>>>((const float*)qkv, ld, (float*)ctx, ldo, lse, lens, S, H, scale);
-    else if (dtype == FS2_BF16) attn_fwd_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (bf16_t*)ctx, ldo, lse, lens, S, H, scale);
+    else if (dtype == FS2_BF16) attn_fwd_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (bf16_t*)ctx, ldo, lse, lens, S, H, scale);
     else { fs2_set_error("attn_fwd: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("attn_fwd");
     return FS2_OK;
@@ -398,10 +735,8 @@ extern "C" int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
         attn_bwd_dq_kernel<float><<<grid, 256, 0, stream>>>((const float*)qkv, ld, (const float*)dctx, ldo, lse, delta, (float*)dqkv, lens, S, H, scale);
     } else if (dtype == FS2_BF16) {
         attn_delta_kernel<bf16_t><<<fs2_cdiv(rows * H, 4), 256, 0, stream>>>((const bf16_t*)ctx, (const bf16_t*)dctx, delta, rows, S, H);
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
-        attn_bwd_dkv_kernel<bf16_t><<<grid, 256, dyn, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
-        attn_bwd_dq_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
+        attn_bwd_dkv_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
+        attn_bwd_dq_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
     } else { fs2_set_error("attn_bwd: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("attn_bwd");
     return FS2_OK;

@@ -395,6 +395,126 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+
+// ---- bf16 weight gradient on v_mfma_f32_32x32x16_bf16 ------------------------------------------------------
+// Both operands are ROW(m)-major in HBM (the reduction index is the slow dimension), so the MFMA fragments
+// (8 consecutive k = 8 consecutive ROWS for one column) are read with gfx950's transposing LDS load
+// ds_read_b64_tr_b16: a 16-lane group supplies 16 x 8-byte addresses forming a [4 rows][16 cols] block and
+// lane i receives column i of the 4 rows.  Tiles are staged untransposed ([64 rows][128 cols] bf16, 256-B rows)
+// with the 64-B column chunk XOR-swizzled by (row & 3) so the 4 rows of one transposing read hit 4 different
+// bank quarters.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int wg_swz(int row, int c16) { return row * 256 + ((((c16 >> 2) ^ (row & 3))) << 6) + ((c16 & 3) << 4); }
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 256];   // [buf][dY|X][64 rows][256 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
+    int bx = blockIdx.x;
+    const int tile_n = bx % ntn; bx /= ntn;
+    const int tile_c = bx % ntc; bx /= ntc;
+    const int tap = bx;
+    const int n0 = tile_n * 128, c0 = tile_c * 128;
+    const int shift = tap * a.dil - a.pad;
+    const int mbeg = blockIdx.y * a.rows_per_split;
+    const int mend = min(a.M, mbeg + a.rows_per_split);
+    if (mbeg >= mend) return;
+    const bf16_t* dY = reinterpret_cast<const bf16_t*>(a.dY);
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
+
+    const int sr = tid >> 4, sc = tid & 15;      // staging: rows sr + 16 i, 16-B chunk sc
+    const bool ncol_ok = (n0 + sc * 8) < a.N, ccol_ok = (c0 + sc * 8) < a.Cin;
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = mt + sr + 16 * i;
+            uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+            if (m < mend) {
+                if (ncol_ok) va = *reinterpret_cast<const uint4*>(dY + (size_t)m * a.lddy + n0 + sc * 8);
+                int ts = (m % a.S) + shift;
+                if (ccol_ok && ts >= 0 && ts < a.S) vb = *reinterpret_cast<const uint4*>(X + (size_t)(m + shift) * a.ldx + c0 + sc * 8);
+            }
+            ra[i] = va; rb[i] = vb;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* As = smem + buf * 32768;
+        unsigned char* Bs = As + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int off = wg_swz(sr + 16 * i, sc);
+            *reinterpret_cast<uint4*>(As + off) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + off) = rb[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int li = lane & 15, g = lane >> 4, h = g >> 1;
+    // per-lane constant parts of the transposing-read address: row-in-kstep = 8h + (li>>2) (+4 for the second half),
+    // column = 64*w + 32*blk + 16*(g&1) + 4*(li&3)
+    const int rrow = 8 * h + (li >> 2);
+    const int acol = wm * 64 + 16 * (g & 1) + 4 * (li & 3);
+    const int bcol = wn * 64 + 16 * (g & 1) + 4 * (li & 3);
+    typedef __attribute__((address_space(3))) s16x4* lds_s4;
+    auto tr_read = [&](const unsigned char* base, int row, int col) -> s16x4 {
+        int off = row * 256 + ((((col >> 5) ^ (row & 3))) << 6) + ((col & 31) << 1);
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + off));
+    };
+    int nt = (mend - mbeg + 63) / 64;
+    load_tile(mbeg);
+    store_tile(0);
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        if (it + 1 < nt) load_tile(mbeg + (it + 1) * 64);
+        const unsigned char* As = smem + (it & 1) * 32768;
+        const unsigned char* Bs = As + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s16x8 af[2], bf[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                s16x4 lo = tr_read(As, ks * 16 + rrow, acol + blk * 32);
+                s16x4 hi = tr_read(As, ks * 16 + rrow + 4, acol + blk * 32);
+                af[blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                lo = tr_read(Bs, ks * 16 + rrow, bcol + blk * 32);
+                hi = tr_read(Bs, ks * 16 + rrow + 4, bcol + blk * 32);
+                bf[blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mb]),
+                                                                          __builtin_bit_cast(bf16x8, bf[nb]), acc[mb][nb], 0, 0, 0);
+        }
+        if (it + 1 < nt) store_tile((it + 1) & 1);
+        __syncthreads();
+    }
+    const int fl = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int c = c0 + wn * 64 + nb * 32 + fl;
+        if (c >= a.Cin) continue;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n = n0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n >= a.N) continue;
+                atomicAdd(a.dW + ((size_t)n * a.Cin + c) * a.taps + tap, acc[mb][nb][r]);
+            }
+    }
+}
+
 extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int S,
                               int taps, int dil, int pad, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(dY && X && dW, "conv_wgrad: null pointer");
@@ -408,14 +528,17 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     // split rows so that ~1024 workgroups exist, each covering a multiple of 32 rows (>= 256 rows).
     long want = (1024 + tiles - 1) / tiles;
     long rps = (M + want - 1) / want;
-    rps = ((rps + 31) / 32) * 32;
+    rps = ((rps + 63) / 64) * 64;
     if (rps < 256) rps = 256;
     a.rows_per_split = (int)rps;
     int splits = fs2_cdiv(M, rps);
     dim3 grid((unsigned)tiles, (unsigned)splits);
     if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
-    else if (dtype == FS2_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
-    else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }
+    else if (dtype == FS2_BF16) {
+        bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
+        if (fast) conv_wgrad_bf16_kernel<<<grid, 256, 0, stream>>>(a);
+        else conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
+    } else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("conv_wgrad");
     return FS2_OK;
 }

@@ -6,6 +6,7 @@
 #include "fs2_common.h"
 
 #define FS2_LN_MAXV 8   // C <= 8*256 = 2048
+#define FS2_LN_BWD_GRID 1024
 
 struct LnArgs {
     void* y;               // in: GEMM output (bias included); overwritten with z = drop_pre(y) + res  (saved for bwd)
@@ -124,6 +125,7 @@ struct LnBwdArgs {
     const void* d1_add;    // optional tensor added into d1 (fuses the "+ upstream residual gradient")
     void* d1; void* d2;    // either may be null
     float* dgamma; float* dbeta;
+    float* partial;        // workspace [grid][2][C]
     int rows, S, C;
     float p_pre, p_post; uint64_t seed_pre, seed_post;
     const uint64_t* seed_dev;
@@ -213,7 +215,8 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
             }
         }
     }
-    // block reduction of dgamma / dbeta partials: 4 waves -> LDS -> wave 0 -> atomics
+    // block reduction of dgamma / dbeta partials: 4 waves -> LDS -> wave 0 -> partial[block][2][C]
+    // (a second tiny kernel sums the per-block partials: no same-address atomic storm)
 #pragma unroll
     for (int i = 0; i < FS2_LN_MAXV; ++i) {
         int c = lane * 4 + i * 256;
@@ -224,7 +227,7 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
         if (w == 0) {
             float4 t = ag[i];
             for (int k = 1; k < 4; ++k) { float4 o = *reinterpret_cast<float4*>(&s_red[k][lane * 4]); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-            atomicAdd(a.dgamma + c, t.x); atomicAdd(a.dgamma + c + 1, t.y); atomicAdd(a.dgamma + c + 2, t.z); atomicAdd(a.dgamma + c + 3, t.w);
+            *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.x * 2) * a.C + c) = t;
         }
         __syncthreads();
         *reinterpret_cast<float4*>(&s_red[w][lane * 4]) = ab[i];
@@ -232,14 +235,23 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
         if (w == 0) {
             float4 t = ab[i];
             for (int k = 1; k < 4; ++k) { float4 o = *reinterpret_cast<float4*>(&s_red[k][lane * 4]); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-            atomicAdd(a.dbeta + c, t.x); atomicAdd(a.dbeta + c + 1, t.y); atomicAdd(a.dbeta + c + 2, t.z); atomicAdd(a.dbeta + c + 3, t.w);
+            *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.x * 2 + 1) * a.C + c) = t;
         }
     }
 }
 
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 2 * C + c];
+    if (c < C) dgamma[c] += s; else dbeta[c - C] += s;
+}
+
 extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
-                          const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta, int B,
-                          int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
+                          const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
+                          float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
                           const uint64_t* seed_dev, int relu_bwd, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(z && dout && gamma && mean && rstd && dgamma && dbeta, "ln_bwd: null pointer");
     FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * FS2_LN_MAXV, "ln_bwd: unsupported C=%d", C);
@@ -249,12 +261,15 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     a.z = z; a.dout = dout; a.gamma = gamma; a.lens = lens; a.mean = mean; a.rstd = rstd; a.d1_add = d1_add; a.d1 = d1; a.d2 = d2;
     a.dgamma = dgamma; a.dbeta = dbeta; a.rows = B * S; a.S = S; a.C = C; a.p_pre = p_pre; a.p_post = p_post;
     a.seed_pre = seed_pre; a.seed_post = seed_post; a.seed_dev = seed_dev; a.relu_bwd = relu_bwd;
+    FS2_CHECK_ARG(partial_ws, "ln_bwd: partial_ws (FS2_LN_BWD_GRID*2*C floats) is required");
+    a.partial = partial_ws;
     if (a.rows == 0) return FS2_OK;
     int grid = fs2_cdiv(a.rows, 4);
-    if (grid > 1024) grid = 1024;
+    if (grid > FS2_LN_BWD_GRID) grid = FS2_LN_BWD_GRID;
     if (dtype == FS2_F32) ln_bwd_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) ln_bwd_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
     else { fs2_set_error("ln_bwd: dtype"); return FS2_EDTYPE; }
+    ln_bwd_reduce_kernel<<<fs2_cdiv(2 * C, 256), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
     FS2_CHECK_LAUNCH("ln_bwd");
     return FS2_OK;
 }

@@ -131,8 +131,9 @@ def ln_bwd(z, dout, gamma, lens, mean, rstd, dgamma, dbeta, B, S, want_d1=True, 
     C = z.shape[-1]
     d1 = torch.empty_like(z) if want_d1 else None
     d2 = torch.empty_like(z) if want_d2 else None
+    ws = torch.empty(1024 * 2 * C, device=z.device, dtype=torch.float32)
     _lib.call("fs2_ln_bwd", _p(z), _p(dout), _p(gamma), _p(lens), _p(mean), _p(rstd), _p(d1_add), _p(d1), _p(d2),
-              _p(dgamma), _p(dbeta), B, S, C, p_pre, seed_pre, p_post, seed_post, _p(seed_dev), int(relu_bwd), dt(z), _stream())
+              _p(dgamma), _p(dbeta), _p(ws), B, S, C, p_pre, seed_pre, p_post, seed_post, _p(seed_dev), int(relu_bwd), dt(z), _stream())
     return d1, d2
 
 
