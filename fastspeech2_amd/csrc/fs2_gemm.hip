@@ -35,6 +35,7 @@ struct ConvGemmArgs {
     int act; float slope;          // output activation
     int in_act; float in_slope;    // activation applied to X on load (leaky-relu prologue of HiFi-GAN)
     int accumulate; float out_scale;
+    int vec_ok;                    // Y / R rows are 16-byte addressable (ld % elems-per-16B == 0, aligned bases)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -76,8 +77,11 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (a.N + 127) >> 7;
-    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    // M-fastest rasterisation: consecutive workgroups (which the dispatcher deals round-robin to the 8 XCDs) share
+    // one weight slice (stays hot in every XCD's L2) and XCD x always sees M-tiles == x (mod 8), so its slice of the
+    // activations is also L2-resident across the N sweep.
+    const int ntm = (a.M + 127) >> 7;
+    const int tile_m = blockIdx.x % ntm, tile_n = blockIdx.x / ntm;
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
         }
     }
 
-    // staging assignment: thread -> 16-B chunk c of rows r_i = (tid>>3) + 32 i
+    // staging assignment: thread -> 16-B chunk sc of rows sr + 32 i
     const int sc = tid & 7, sr = tid >> 3;
     int a_t[4];   // time index of the A row within its sequence, or a large negative if m >= M
     size_t a_off[4];
@@ -113,8 +117,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
     const int nkc = (a.Cin + BK - 1) / BK;
     const int nk = a.taps * nkc;
 
-    uint4 ra[4], rb[4];
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
         int tap = kt / nkc, kc = kt - tap * nkc;
         int shift = tap * a.dil - a.pad;
         int col = kc * BK + sc * EPC;
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
             for (int i = 0; i < 4; ++i) ra[i] = (sizeof(T) == 4) ? act_chunk_f32(ra[i], a.in_slope) : act_chunk_bf16(ra[i], a.in_slope);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
         unsigned char* As = smem + buf * 32768;
         unsigned char* Bs = As + 16384;
 #pragma unroll
@@ -161,12 +164,8 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fl = lane & 31, fh = lane >> 5;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const unsigned char* As = smem + (kt & 1) * 32768;
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * 32768;
         const unsigned char* Bs = As + 16384;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -201,36 +200,94 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
                             __builtin_bit_cast(bf16x8, af[mb]), __builtin_bit_cast(bf16x8, bf[nb]), acc[mb][nb], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) store_tile((kt + 1) & 1);
+    };
+
+    // 3-stage software pipeline: two register sets hold K-tiles t+1 / t+2 in flight while tile t is consumed from LDS
+    // (global loads get two tile-times to land; one barrier per K-tile).
+    uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+    load_tile(0, ra0, rb0);
+    if (nk > 1) load_tile(1, ra1, rb1);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) load_tile(kt + 2, ra0, rb0);
+        compute(0);
+        if (kt + 1 < nk) store_tile(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) load_tile(kt + 3, ra1, rb1);
+        compute(1);
+        if (kt + 2 < nk) store_tile(0, ra0, rb0);
         __syncthreads();
     }
 
-    // epilogue: C layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue: bias + activation in registers, tile staged through LDS as f32 [128][128], then whole 16-byte
+    // row segments are written (and the residual / gate operand read) coalesced.
+    // C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        int n = n0 + wn * 64 + nb * 32 + fl;
-        if (n >= a.N) continue;
-        float bv = a.bias ? a.bias[n] : 0.f;
+        int cl = wn * 64 + nb * 32 + fl;
+        int n = n0 + cl;
+        float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= a.M) continue;
-                float v = apply_act(acc[mb][nb][r] + bv, a.act, a.slope);
-                if (R) {
-                    float rv = Elem<T>::ld(R + (size_t)m * a.ldr + n);
-                    if (a.act == FS2_ACT_GATE) v = rv > 0.f ? v : 0.f;   // ReLU backward gate: R holds the ReLU output
-                    else v += rv;
-                }
-                v *= a.out_scale;
-                if (a.lens) {
-                    int b = m / a.S;
-                    if (m - b * a.S >= a.lens[b]) v = 0.f;
-                }
-                T* yp = Y + (size_t)m * a.ldy + n;
-                if (a.accumulate) v += Elem<T>::ld(yp);
-                Elem<T>::st(yp, v);
+                int rl = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float v = acc[mb][nb][r] + bv;
+                if (a.act != FS2_ACT_GATE) v = apply_act(v, a.act, a.slope);
+                tile[rl * 128 + cl] = v;
+            }
+    }
+    __syncthreads();
+    constexpr int EPT = EPC;                 // elements per 16-byte global store
+    constexpr int CPR = 128 / EPT;           // 16-byte chunks per tile row
+    const bool gate = a.act == FS2_ACT_GATE;
+#pragma unroll 4
+    for (int it = 0; it < (128 * CPR) / 256; ++it) {
+        int idx = tid + 256 * it;
+        int rl = idx / CPR, cc = (idx % CPR) * EPT;
+        int m = m0 + rl, n = n0 + cc;
+        if (m >= a.M || n >= a.N) continue;
+        float v[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {
+            float4 t = *reinterpret_cast<const float4*>(tile + rl * 128 + cc + e);
+            v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+        }
+        bool padrow = false;
+        if (a.lens) { int b = m / a.S; padrow = (m - b * a.S) >= a.lens[b]; }
+        T* yp = Y + (size_t)m * a.ldy + n;
+        const T* rp = R ? R + (size_t)m * a.ldr + n : nullptr;
+        if (a.vec_ok && n + EPT <= a.N) {
+            if (rp) {
+                float rv[EPT];
+                uint4 rr = *reinterpret_cast<const uint4*>(rp);
+                if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&rr); for (int e = 0; e < 4; ++e) rv[e] = f[e]; }
+                else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr); for (int e = 0; e < 4; ++e) { rv[2 * e] = __uint_as_float(u[e] << 16); rv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); } }
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) v[e] = gate ? (rv[e] > 0.f ? v[e] : 0.f) : v[e] + rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { v[e] *= a.out_scale; if (padrow) v[e] = 0.f; }
+            if (a.accumulate) {
+                uint4 yy = *reinterpret_cast<const uint4*>(yp);
+                if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&yy); for (int e = 0; e < 4; ++e) v[e] += f[e]; }
+                else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy); for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); } }
+            }
+            uint4 o;
+            if constexpr (sizeof(T) == 4) { float* f = reinterpret_cast<float*>(&o); for (int e = 0; e < 4; ++e) f[e] = v[e]; }
+            else { uint32_t* u = reinterpret_cast<uint32_t*>(&o); for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16); }
+            *reinterpret_cast<uint4*>(yp) = o;
+        } else {
+            for (int e = 0; e < EPT && n + e < a.N; ++e) {
+                float x = v[e];
+                if (rp) { float rv = Elem<T>::ld(rp + e); x = gate ? (rv > 0.f ? x : 0.f) : x + rv; }
+                x *= a.out_scale;
+                if (padrow) x = 0.f;
+                if (a.accumulate) x += Elem<T>::ld(yp + e);
+                Elem<T>::st(yp + e, x);
             }
         }
     }
@@ -252,6 +309,7 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = (long)taps * Cin; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps; a.dil = dil; a.pad = pad; a.act = act;
     a.slope = slope; a.in_act = in_act; a.in_slope = in_slope; a.accumulate = accumulate; a.out_scale = out_scale;
+    a.vec_ok = (ldy % epc == 0) && (((uintptr_t)Y & 15) == 0) && (!R || ((ldr % epc == 0) && (((uintptr_t)R & 15) == 0)));
     long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     if (dtype == FS2_F32) conv_gemm_kernel<float><<<(unsigned)grid, 256, 0, stream>>>(a);
     else conv_gemm_kernel<bf16_t><<<(unsigned)grid, 256, 0, stream>>>(a);

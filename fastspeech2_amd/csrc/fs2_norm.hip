@@ -6,7 +6,7 @@
 #include "fs2_common.h"
 
 #define FS2_LN_MAXV 8   // C <= 8*256 = 2048
-#define FS2_LN_BWD_GRID 1024
+#define FS2_LN_BWD_GRID 512
 
 struct LnArgs {
     void* y;               // in: GEMM output (bias included); overwritten with z = drop_pre(y) + res  (saved for bwd)
@@ -240,13 +240,22 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
     }
 }
 
+// sums the per-block partials: block = 32 channels x 8 row-groups; coalesced 128-B reads, LDS tree at the end.
 __global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * C) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 2 * C + c];
-    if (c < C) dgamma[c] += s; else dbeta[c - C] += s;
+    __shared__ float s[8][32];
+    int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    float acc = 0.f;
+    if (c < 2 * C)
+        for (int b = rg; b < nblocks; b += 8) acc += partial[(size_t)b * 2 * C + c];
+    s[rg][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (rg == 0 && c < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x];
+        if (c < C) dgamma[c] += t; else dbeta[c - C] += t;
+    }
 }
 
 extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
@@ -269,7 +278,7 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     if (dtype == FS2_F32) ln_bwd_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) ln_bwd_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
     else { fs2_set_error("ln_bwd: dtype"); return FS2_EDTYPE; }
-    ln_bwd_reduce_kernel<<<fs2_cdiv(2 * C, 256), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
+    ln_bwd_reduce_kernel<<<fs2_cdiv(2 * C, 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
     FS2_CHECK_LAUNCH("ln_bwd");
     return FS2_OK;
 }

@@ -68,7 +68,7 @@ int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, 
                uint64_t seed_post, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 /* d1 = dz (+ d1_add), d2 = dz * dropmask_pre * (relu_bwd ? z>0 : 1); dgamma/dbeta += column sums.
  * partial_ws: caller workspace of FS2_LN_BWD_GRID*2*C floats (per-block partial sums, reduced by a 2nd launch). */
-#define FS2_LN_BWD_GRID 1024
+#define FS2_LN_BWD_GRID 512
 int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
                const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
                float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, const uint64_t* seed_dev,
