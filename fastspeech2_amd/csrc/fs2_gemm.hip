@@ -318,19 +318,19 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
 }
 
 // ------------------------------------------------------------------ weight packing
-// torch Conv1d weight (Cout, Cin, k) fp32 -> forward pack  Wf[n][j][c]       = W[n][c][j]
-//                                          -> dgrad pack    Wd[c][j][n]       = W[n][c][k-1-j]
-// Linear weight (N, K) is the k=1 case.  Output in the compute dtype.
+// Master conv weights are STORED tap-major, W[n][j][c] (the nn.Parameter the user sees is the permuted view
+// (Cout, Cin, k) of that storage), i.e. already in the K-contiguous order the forward GEMM wants:
+//   forward pack  Wf[n][j][c] = W[n][j][c]           (a dtype cast; not needed at all for f32 compute)
+//   dgrad pack    Wd[c][j][n] = W[n][k-1-j][c]       (tap flip + transpose)
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin, int k) {
     size_t total = (size_t)Cout * Cin * k;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        // i indexes the forward pack (coalesced writes): i = (n*k + j)*Cin + c
         int c = (int)(i % Cin);
         size_t q = i / Cin;
         int j = (int)(q % k);
         int n = (int)(q / k);
-        float v = w[((size_t)n * Cin + c) * k + j];
+        float v = w[i];
         if (wf) Elem<T>::st(wf + i, v);
         if (wd) Elem<T>::st(wd + ((size_t)c * k + (k - 1 - j)) * Cout + n, v);
     }
@@ -348,7 +348,8 @@ extern "C" int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int
 }
 
 // ------------------------------------------------------------------ weight gradient (TN contraction over rows)
-// dW[n][c][j] (torch layout (Cout,Cin,k), fp32, atomically accumulated) = sum_m dY[m][n] * X[m + j*dil - pad][c]
+// dW[n][j][c] (tap-major master layout, fp32, atomically accumulated; lanes run along c -> coalesced atomics)
+//   = sum_m dY[m][n] * X[m + j*dil - pad][c]
 // Block: 128 (n) x 128 (c) output tile for one tap, split-K over row ranges; K-tile = 32 rows.
 // f32: LDS tiles [32 rows][128] f32, fragments by ds_read_b32 (lanes along n / c: conflict-free),
 //      v_mfma_f32_32x32x2_f32.
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 int n = n0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n >= a.N) continue;
-                atomicAdd(a.dW + ((size_t)n * a.Cin + c) * a.taps + tap, acc[mb][nb][r]);
+                atomicAdd(a.dW + ((size_t)n * a.taps + tap) * a.Cin + c, acc[mb][nb][r]);
             }
     }
 }
@@ -466,59 +467,74 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int wg_swz(int row, int c16) { return row * 256 + ((((c16 >> 2) ^ (row & 3))) << 6) + ((c16 & 3) << 4); }
 
-__global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 256];   // [buf][dY|X][64 rows][256 B]
+// One workgroup = 128 (n) x 128 (c) outputs for a GROUP of up to TPB adjacent taps, over a range of K-tiles.
+// K-tiles are 64 rows and never straddle a sequence, so the X tile is staged ONCE with a halo of (TPB-1)*dil rows
+// (rows outside the sequence zero-filled) and every tap of the group reads it at a different row offset: the dY and
+// X tiles are fetched once per tap GROUP instead of once per tap.
+template <int TPB>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
+    constexpr int XROWS = 64 + 8;                       // halo capacity: (TPB-1)*dil <= 8
+    constexpr int A_BYTES = 64 * 256, X_BYTES = XROWS * 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [buf][dY 64 rows | X 72 rows][256 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
     int bx = blockIdx.x;
     const int tile_n = bx % ntn; bx /= ntn;
     const int tile_c = bx % ntc; bx /= ntc;
-    const int tap = bx;
+    const int tap0 = bx * TPB;
+    const int ntap = min(TPB, a.taps - tap0);
     const int n0 = tile_n * 128, c0 = tile_c * 128;
-    const int shift = tap * a.dil - a.pad;
-    const int mbeg = blockIdx.y * a.rows_per_split;
-    const int mend = min(a.M, mbeg + a.rows_per_split);
-    if (mbeg >= mend) return;
+    const int shift0 = tap0 * a.dil - a.pad;
+    const int tps = (a.S + 63) >> 6;                    // K-tiles per sequence
+    const int nunits = (a.M / a.S) * tps;
+    const int ubeg = blockIdx.y * a.rows_per_split;     // here: units per split
+    const int uend = min(nunits, ubeg + a.rows_per_split);
+    if (ubeg >= uend) return;
     const bf16_t* dY = reinterpret_cast<const bf16_t*>(a.dY);
     const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
 
-    const int sr = tid >> 4, sc = tid & 15;      // staging: rows sr + 16 i, 16-B chunk sc
+    const int sr = tid >> 4, sc = tid & 15;
     const bool ncol_ok = (n0 + sc * 8) < a.N, ccol_ok = (c0 + sc * 8) < a.Cin;
-    uint4 ra[4], rb[4];
-    auto load_tile = [&](int mt) {
+    uint4 ra[4], rb[5];
+    auto load_tile = [&](int u) {
+        int seq = u / tps, t0 = (u - seq * tps) * 64;
+        size_t base = (size_t)seq * a.S;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int m = mt + sr + 16 * i;
-            uint4 va = make_uint4(0, 0, 0, 0), vb = va;
-            if (m < mend) {
-                if (ncol_ok) va = *reinterpret_cast<const uint4*>(dY + (size_t)m * a.lddy + n0 + sc * 8);
-                int ts = (m % a.S) + shift;
-                if (ccol_ok && ts >= 0 && ts < a.S) vb = *reinterpret_cast<const uint4*>(X + (size_t)(m + shift) * a.ldx + c0 + sc * 8);
-            }
-            ra[i] = va; rb[i] = vb;
+            int t = t0 + sr + 16 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ncol_ok && t < a.S) v = *reinterpret_cast<const uint4*>(dY + (base + t) * a.lddy + n0 + sc * 8);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int xr = sr + 16 * i;                       // halo-tile row 0..79 (only < XROWS stored)
+            int t = t0 + shift0 + xr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ccol_ok && xr < XROWS && t >= 0 && t < a.S) v = *reinterpret_cast<const uint4*>(X + (base + t) * a.ldx + c0 + sc * 8);
+            rb[i] = v;
         }
     };
     auto store_tile = [&](int buf) {
-        unsigned char* As = smem + buf * 32768;
-        unsigned char* Bs = As + 16384;
+        unsigned char* As = smem + buf * (A_BYTES + X_BYTES);
+        unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int off = wg_swz(sr + 16 * i, sc);
-            *reinterpret_cast<uint4*>(As + off) = ra[i];
-            *reinterpret_cast<uint4*>(Bs + off) = rb[i];
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + wg_swz(sr + 16 * i, sc)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (sr + 16 * i < XROWS) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 16 * i, sc)) = rb[i];
     };
-    f32x16 acc[2][2];
+    f32x16 acc[TPB][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < TPB; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
     const int li = lane & 15, g = lane >> 4, h = g >> 1;
-    // per-lane constant parts of the transposing-read address: row-in-kstep = 8h + (li>>2) (+4 for the second half),
-    // column = 64*w + 32*blk + 16*(g&1) + 4*(li&3)
     const int rrow = 8 * h + (li >> 2);
     const int acol = wm * 64 + 16 * (g & 1) + 4 * (li & 3);
     const int bcol = wn * 64 + 16 * (g & 1) + 4 * (li & 3);
@@ -527,34 +543,44 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(WgradArgs a) {
         int off = row * 256 + ((((col >> 5) ^ (row & 3))) << 6) + ((col & 31) << 1);
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + off));
     };
-    int nt = (mend - mbeg + 63) / 64;
-    load_tile(mbeg);
+    load_tile(ubeg);
     store_tile(0);
     __syncthreads();
-    for (int it = 0; it < nt; ++it) {
-        if (it + 1 < nt) load_tile(mbeg + (it + 1) * 64);
-        const unsigned char* As = smem + (it & 1) * 32768;
-        const unsigned char* Bs = As + 16384;
+    for (int u = ubeg; u < uend; ++u) {
+        if (u + 1 < uend) load_tile(u + 1);
+        const int buf = (u - ubeg) & 1;
+        const unsigned char* As = smem + buf * (A_BYTES + X_BYTES);
+        const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s16x8 af[2], bf[2];
+            s16x8 af[2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 s16x4 lo = tr_read(As, ks * 16 + rrow, acol + blk * 32);
                 s16x4 hi = tr_read(As, ks * 16 + rrow + 4, acol + blk * 32);
                 af[blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                lo = tr_read(Bs, ks * 16 + rrow, bcol + blk * 32);
-                hi = tr_read(Bs, ks * 16 + rrow + 4, bcol + blk * 32);
-                bf[blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int t = 0; t < TPB; ++t) {
+                if (t < ntap) {
+                    s16x8 bf[2];
+                    int xo = t * a.dil;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mb]),
-                                                                          __builtin_bit_cast(bf16x8, bf[nb]), acc[mb][nb], 0, 0, 0);
+                    for (int blk = 0; blk < 2; ++blk) {
+                        s16x4 lo = tr_read(Bs, ks * 16 + rrow + xo, bcol + blk * 32);
+                        s16x4 hi = tr_read(Bs, ks * 16 + rrow + 4 + xo, bcol + blk * 32);
+                        bf[blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[t][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, af[mb]), __builtin_bit_cast(bf16x8, bf[nb]), acc[t][mb][nb], 0, 0, 0);
+                }
+            }
         }
-        if (it + 1 < nt) store_tile((it + 1) & 1);
+        if (u + 1 < uend) store_tile(buf ^ 1);
         __syncthreads();
     }
     const int fl = lane & 31, fh = lane >> 5;
@@ -568,9 +594,31 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 int n = n0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n >= a.N) continue;
-                atomicAdd(a.dW + ((size_t)n * a.Cin + c) * a.taps + tap, acc[mb][nb][r]);
+                float* dst = a.dW + ((size_t)n * a.taps + tap0) * a.Cin + c;
+#pragma unroll
+                for (int t = 0; t < TPB; ++t)
+                    if (t < ntap) atomicAdd(dst + (size_t)t * a.Cin, acc[t][mb][nb][r]);
             }
     }
+}
+
+template <int TPB>
+static int launch_wgrad_bf16(WgradArgs a, int S_eff, hipStream_t stream) {
+    a.S = S_eff;
+    const int dyn = 2 * (64 * 256 + 72 * 256);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
+    int groups = (a.taps + TPB - 1) / TPB;
+    long tiles = (long)fs2_cdiv(a.N, 128) * fs2_cdiv(a.Cin, 128) * groups;
+    int tps = (a.S + 63) / 64;
+    long units = (long)(a.M / a.S) * tps;
+    long want = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU in total
+    long ups = (units + want - 1) / want;
+    if (ups < 4) ups = 4;
+    a.rows_per_split = (int)ups;
+    dim3 grid((unsigned)tiles, (unsigned)fs2_cdiv(units, ups));
+    conv_wgrad_bf16_kernel<TPB><<<grid, 256, dyn, stream>>>(a);
+    return 0;
 }
 
 extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int S,
@@ -594,7 +642,8 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) {
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
-        if (fast) conv_wgrad_bf16_kernel<<<grid, 256, 0, stream>>>(a);
+        if (fast && taps == 1) launch_wgrad_bf16<1>(a, M, stream);            // no taps: one "sequence" of M rows
+        else if (fast && 2 * dil <= 8 && M % S == 0) launch_wgrad_bf16<3>(a, S, stream);
         else conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
     } else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("conv_wgrad");

@@ -85,9 +85,13 @@ class Engine:
             return self._packed
         packed = {}
         for key, w, b in self._conv_list():
+            if w.dim() == 3:
+                w = w.permute(0, 2, 1)          # the contiguous tap-major storage [Cout][k][Cin]
             prev = self._packed.get(key)
             wf = prev[0] if prev is not None else None
             wd = prev[1] if (prev is not None and prev[1] is not None) else None
+            if self.cdt == torch.float32:
+                wf = None                        # f32 compute reads the master weights in place
             wf, wd = ops.pack_weight(w, self.cdt, want_fwd=True, want_dgrad=need_dgrad, wf=wf, wd=wd if need_dgrad else None)
             packed[key] = (wf, wd if need_dgrad else (prev[1] if prev is not None else None), b, w.shape)
         self._packed = packed
@@ -135,6 +139,8 @@ class Engine:
         return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res)
 
     def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0):
+        if gw.dim() == 3:
+            gw = gw.permute(0, 2, 1)            # tap-major storage of the gradient
         ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad)
         ops.colsum(dy, gb)
 

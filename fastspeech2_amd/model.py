@@ -261,8 +261,7 @@ class FastSpeech2(nn.Module):
         flat = torch.zeros(total, device=device, dtype=torch.float32)
         grad = torch.zeros(total, device=device, dtype=torch.float32)
         for n, p in pairs:
-            o = offsets[n]
-            view = flat[o:o + p.numel()].view(p.shape)
+            view = self._view(flat, offsets[n], p.shape)
             view.copy_(p.data.to(device=device, dtype=torch.float32))
             p.data = view
             p.grad = None
@@ -276,6 +275,18 @@ class FastSpeech2(nn.Module):
         self._flat_names = [n for n, _ in pairs]
         self._engine = Engine(self, device)
 
+    @staticmethod
+    def _view(buf, offset, shape):
+        """Parameter view into a flat buffer.  Conv weights (Cout, Cin, k>1) are STORED tap-major [Cout][k][Cin]
+        (the K-contiguous order the MFMA contraction and the coalesced weight-gradient epilogue want); the tensor
+        handed to torch is the permuted view, so state_dict()/load_state_dict() still see (Cout, Cin, k)."""
+        n = 1
+        for s_ in shape:
+            n *= s_
+        if len(shape) == 3 and shape[2] > 1:
+            return buf[offset:offset + n].view(shape[0], shape[2], shape[1]).permute(0, 2, 1)
+        return buf[offset:offset + n].view(shape)
+
     def flat_parameters(self):
         return self._flat
 
@@ -284,14 +295,12 @@ class FastSpeech2(nn.Module):
 
     def grad_view(self, name):
         p = dict(self.named_parameters())[name]
-        o = self._flat_offsets[name]
-        return self._flat_grad[o:o + p.numel()].view(p.shape)
+        return self._view(self._flat_grad, self._flat_offsets[name], p.shape)
 
     def attach_grads(self):
         """Point every trainable Parameter's .grad at its slice of the flat gradient buffer."""
         for n, p in self._trainable_in_backward_order():
-            o = self._flat_offsets[n]
-            p.grad = self._flat_grad[o:o + p.numel()].view(p.shape)
+            p.grad = self._view(self._flat_grad, self._flat_offsets[n], p.shape)
 
     def train(self, mode=True):
         self._invalidate()
@@ -432,10 +441,9 @@ class ScheduledOptim:
         for i, p in enumerate(params):
             n = names[id(p)]
             if n in offs and self._adam_step > 0:
-                o = offs[n]
                 state[i] = {"step": torch.tensor(float(self._adam_step)),
-                            "exp_avg": self._m[o:o + p.numel()].view(p.shape).clone(),
-                            "exp_avg_sq": self._v[o:o + p.numel()].view(p.shape).clone()}
+                            "exp_avg": self.model._view(self._m, offs[n], p.shape).clone(),
+                            "exp_avg_sq": self.model._view(self._v, offs[n], p.shape).clone()}
         group = {"lr": getattr(self, "last_lr", 0.001), "betas": self.betas, "eps": self.eps,
                  "weight_decay": self.weight_decay, "amsgrad": False, "params": list(range(len(params)))}
         return {"state": state, "param_groups": [group]}
@@ -449,9 +457,8 @@ class ScheduledOptim:
             n = names[id(p)]
             if n not in offs:
                 continue
-            o = offs[n]
-            self._m[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
-            self._v[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
+            self.model._view(self._m, offs[n], p.shape).copy_(st["exp_avg"])
+            self.model._view(self._v, offs[n], p.shape).copy_(st["exp_avg_sq"])
             self._adam_step = int(float(st["step"]))
 
     def load_state_dict(self, sd):

@@ -42,18 +42,24 @@ def _contig(t):
 
 # ------------------------------------------------------------------ weights
 def pack_weight(w, dtype, want_fwd=True, want_dgrad=True, wf=None, wd=None):
-    """w: (Cout, Cin, k) or (N, K) fp32 -> (Wf [Cout][k][Cin], Wd [Cin][k][Cout]) in `dtype`."""
+    """w: tap-major master weight (Cout, k, Cin) or (N, K) fp32 -> (Wf [Cout][k][Cin], Wd [Cin][k][Cout]) in `dtype`.
+    With dtype == float32 and no explicit output buffer, Wf is w itself (no copy)."""
     w = _contig(w)
     if w.dim() == 2:
         cout, cin, k = w.shape[0], w.shape[1], 1
     else:
-        cout, cin, k = w.shape
+        cout, k, cin = w.shape
+    if want_fwd and wf is None and dtype == torch.float32:
+        wf, want_fwd_copy = w.view(cout, k, cin), False
+    else:
+        want_fwd_copy = want_fwd
     if want_fwd and wf is None:
         wf = torch.empty(cout, k, cin, device=w.device, dtype=dtype)
     if want_dgrad and wd is None:
         wd = torch.empty(cin, k, cout, device=w.device, dtype=dtype)
-    _lib.call("fs2_pack_weight", _p(w), _p(wf) if want_fwd else None, _p(wd) if want_dgrad else None, cout, cin, k,
-              dt(dtype), _stream())
+    if want_fwd_copy or want_dgrad:
+        _lib.call("fs2_pack_weight", _p(w), _p(wf) if want_fwd_copy else None, _p(wd) if want_dgrad else None, cout, cin, k,
+                  dt(dtype), _stream())
     return wf, wd
 
 
@@ -87,7 +93,7 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
 
 
 def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0):
-    """dw (Cout, Cin, k) fp32 += dy^T * shifted x."""
+    """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x."""
     M, N = dy.shape
     Cin = x.shape[1]
     _lib.call("fs2_conv_wgrad", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), M, N, Cin, S, taps, dil, pad, dt(dy),

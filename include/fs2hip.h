@@ -45,9 +45,10 @@ int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bia
                   long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad, int act,
                   float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
                   fs2_stream_t stream);
-/* torch weight (Cout,Cin,k) f32 -> Wf[n][j][c] (forward) and/or Wd[c][j][n] = W[n][c][k-1-j] (data gradient). */
+/* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
+ * -> Wf[n][j][c] (forward: dtype cast) and/or Wd[c][j][n] = W[n][k-1-j][c] (data gradient: tap flip + transpose). */
 int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, fs2_stream_t stream);
-/* dW[n][c][j] += sum_m dY[m][n] * X[m + j*dil - pad][c]   (torch layout (Cout,Cin,k), f32, atomic accumulate) */
+/* dW[n][j][c] += sum_m dY[m][n] * X[m + j*dil - pad][c]   (tap-major master layout, f32, atomic accumulate) */
 int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int S, int taps,
                    int dil, int pad, int dtype, fs2_stream_t stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */

@@ -47,7 +47,7 @@ def test_conv_gemm_fwd(dev, dtype, tol, B, S, Cin, Cout, k, dil):
     pad = dil * (k - 1) // 2
     lens = torch.tensor([S - 7 * i for i in range(B)], dtype=torch.int32)
     xd = x.to(dev).to(dtype)
-    wf, wd = ops.pack_weight(w.to(dev), dtype)
+    wf, wd = ops.pack_weight(w.permute(0, 2, 1).contiguous().to(dev), dtype)      # master weights are tap-major
     xr = xd.float().cpu()
     wr = wf.float().cpu().permute(0, 2, 1).contiguous()
     for use_lens in (False, True):
@@ -71,7 +71,7 @@ def test_conv_grads(dev, dtype, tol, B, S, Cin, Cout, k, dil):
     w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
     dy = torch.randn(B * S, Cout)
     xd, dyd = x.to(dev).to(dtype), dy.to(dev).to(dtype)
-    wf, wd = ops.pack_weight(w.to(dev), dtype)
+    wf, wd = ops.pack_weight(w.permute(0, 2, 1).contiguous().to(dev), dtype)
     xr = xd.float().cpu().double().requires_grad_(True)
     wr = wf.float().cpu().permute(0, 2, 1).contiguous().double().requires_grad_(True)
     y = conv_ref(xr, wr, None, S, dil, pad)
@@ -79,9 +79,9 @@ def test_conv_grads(dev, dtype, tol, B, S, Cin, Cout, k, dil):
     # dgrad: conv of dy with tap-flipped transposed weights, pad' = (k-1)*dil - pad
     dx = ops.conv_gemm(dyd, wd, None, S, taps=k, dil=dil, pad=(k - 1) * dil - pad)
     assert rel_err(dx.float(), xr.grad) < tol
-    dw = torch.zeros(Cout, Cin, k, device=dev)
+    dw = torch.zeros(Cout, k, Cin, device=dev)                                      # tap-major gradient
     ops.conv_wgrad(dyd, xd, dw, S, taps=k, dil=dil, pad=pad)
-    assert rel_err(dw, wr.grad) < (tol if dtype == torch.float32 else 2e-2)
+    assert rel_err(dw.permute(0, 2, 1), wr.grad) < (tol if dtype == torch.float32 else 2e-2)
     db = torch.zeros(Cout, device=dev)
     ops.colsum(dyd, db)
     assert rel_err(db, dyd.float().cpu().double().sum(0)) < 1e-4

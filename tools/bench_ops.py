@@ -27,7 +27,7 @@ def main():
         for (name, Cin, Cout, k) in [("w_1 k9", 256, 1024, 9), ("w_2 k1", 1024, 256, 1), ("qkv", 256, 768, 1), ("fc", 256, 256, 1),
                                      ("postnet k5", 512, 512, 5), ("mel", 256, 80, 1)]:
             x = torch.randn(M, Cin, device=dev).to(dtype)
-            w = torch.randn(Cout, Cin, k, device=dev) / math.sqrt(Cin * k)
+            w = torch.randn(Cout, k, Cin, device=dev) / math.sqrt(Cin * k)
             b = torch.randn(Cout, device=dev)
             wf, wd = ops.pack_weight(w, dtype)
             y = torch.empty(M, Cout, device=dev, dtype=dtype)
@@ -35,7 +35,7 @@ def main():
             fl = 2.0 * M * Cin * Cout * k
             print(f"  fwd {name:12s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF")
             dy = torch.randn(M, Cout, device=dev).to(dtype)
-            dw = torch.zeros(Cout, Cin, k, device=dev)
+            dw = torch.zeros(Cout, k, Cin, device=dev)
             ms = timeit(lambda: ops.conv_wgrad(dy, x, dw, T, taps=k, pad=(k - 1) // 2))
             print(f"  wgrad {name:10s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF")
         H = 2
