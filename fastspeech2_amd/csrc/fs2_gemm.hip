@@ -69,6 +69,65 @@ __device__ __forceinline__ uint4 act_chunk_bf16(uint4 v, float slope) {
     return v;
 }
 
+// final stage of the epilogue (shared by both GEMM kernels): the f32 tile staged in LDS is written out in whole
+// 16-byte row segments; residual / ReLU-gate operand and the accumulate operand are read the same way.
+template <typename T>
+__device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const float* tile, int m0, int n0, int tid) {
+    constexpr int EPC = MmaTraits<T>::EPC;
+    T* Y = reinterpret_cast<T*>(a.Y);
+    const T* R = reinterpret_cast<const T*>(a.R);
+    constexpr int EPT = EPC;                 // elements per 16-byte global store
+    constexpr int CPR = 128 / EPT;           // 16-byte chunks per tile row
+    const bool gate = a.act == FS2_ACT_GATE;
+#pragma unroll 4
+    for (int it = 0; it < (128 * CPR) / 256; ++it) {
+        int idx = tid + 256 * it;
+        int rl = idx / CPR, cc = (idx % CPR) * EPT;
+        int m = m0 + rl, n = n0 + cc;
+        if (m >= a.M || n >= a.N) continue;
+        float v[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {
+            float4 t = *reinterpret_cast<const float4*>(tile + rl * 128 + cc + e);
+            v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+        }
+        bool padrow = false;
+        if (a.lens) { int b = m / a.S; padrow = (m - b * a.S) >= a.lens[b]; }
+        T* yp = Y + (size_t)m * a.ldy + n;
+        const T* rp = R ? R + (size_t)m * a.ldr + n : nullptr;
+        if (a.vec_ok && n + EPT <= a.N) {
+            if (rp) {
+                float rv[EPT];
+                uint4 rr = *reinterpret_cast<const uint4*>(rp);
+                if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&rr); for (int e = 0; e < 4; ++e) rv[e] = f[e]; }
+                else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr); for (int e = 0; e < 4; ++e) { rv[2 * e] = __uint_as_float(u[e] << 16); rv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); } }
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) v[e] = gate ? (rv[e] > 0.f ? v[e] : 0.f) : v[e] + rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { v[e] *= a.out_scale; if (padrow) v[e] = 0.f; }
+            if (a.accumulate) {
+                uint4 yy = *reinterpret_cast<const uint4*>(yp);
+                if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&yy); for (int e = 0; e < 4; ++e) v[e] += f[e]; }
+                else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy); for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); } }
+            }
+            uint4 o;
+            if constexpr (sizeof(T) == 4) { float* f = reinterpret_cast<float*>(&o); for (int e = 0; e < 4; ++e) f[e] = v[e]; }
+            else { uint32_t* u = reinterpret_cast<uint32_t*>(&o); for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16); }
+            *reinterpret_cast<uint4*>(yp) = o;
+        } else {
+            for (int e = 0; e < EPT && n + e < a.N; ++e) {
+                float x = v[e];
+                if (rp) { float rv = Elem<T>::ld(rp + e); x = gate ? (rv > 0.f ? x : 0.f) : x + rv; }
+                x *= a.out_scale;
+                if (padrow) x = 0.f;
+                if (a.accumulate) x += Elem<T>::ld(yp + e);
+                Elem<T>::st(yp + e, x);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
     constexpr int EPC = MmaTraits<T>::EPC;
@@ -241,56 +300,182 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
             }
     }
     __syncthreads();
-    constexpr int EPT = EPC;                 // elements per 16-byte global store
-    constexpr int CPR = 128 / EPT;           // 16-byte chunks per tile row
-    const bool gate = a.act == FS2_ACT_GATE;
-#pragma unroll 4
-    for (int it = 0; it < (128 * CPR) / 256; ++it) {
-        int idx = tid + 256 * it;
-        int rl = idx / CPR, cc = (idx % CPR) * EPT;
-        int m = m0 + rl, n = n0 + cc;
-        if (m >= a.M || n >= a.N) continue;
-        float v[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; e += 4) {
-            float4 t = *reinterpret_cast<const float4*>(tile + rl * 128 + cc + e);
-            v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
-        }
-        bool padrow = false;
-        if (a.lens) { int b = m / a.S; padrow = (m - b * a.S) >= a.lens[b]; }
-        T* yp = Y + (size_t)m * a.ldy + n;
-        const T* rp = R ? R + (size_t)m * a.ldr + n : nullptr;
-        if (a.vec_ok && n + EPT <= a.N) {
-            if (rp) {
-                float rv[EPT];
-                uint4 rr = *reinterpret_cast<const uint4*>(rp);
-                if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&rr); for (int e = 0; e < 4; ++e) rv[e] = f[e]; }
-                else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr); for (int e = 0; e < 4; ++e) { rv[2 * e] = __uint_as_float(u[e] << 16); rv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); } }
-#pragma unroll
-                for (int e = 0; e < EPT; ++e) v[e] = gate ? (rv[e] > 0.f ? v[e] : 0.f) : v[e] + rv[e];
+    gemm_store_tile<T>(a, tile, m0, n0, tid);
+}
+
+// =====================================================================================================
+// LDS-DMA variant (in_act == none, halo (taps-1)*dil <= 16): operands go HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass).  The DMA destination is wave-uniform base +
+// lane*16 (lane-linear), so the bank swizzle is applied to the per-lane SOURCE chunk (guide rule 21): LDS slot
+// (row r, chunk c) receives source chunk c ^ ((r>>1)&7) and fragment reads use the same XOR.
+// For convolutions the activation tile is staged ONCE per Cin-chunk with a halo of (taps-1)*dil rows and every tap
+// reads it at a row offset; only the weight tile changes per tap.  Taps that fall outside the row's own sequence
+// are zeroed on the fragment (per-lane tap-validity bitmask, VALU work hidden under the MFMAs); rows outside
+// [0, M) / columns outside Cin / N are fetched from a zero line.
+__device__ __attribute__((aligned(128))) unsigned int fs2_zero_line[32];
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
+    constexpr int EPC = MmaTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int A_ROWS = 160;                                  // 128 + halo (<= 16), rounded to 20 wave-loads
+    constexpr int A_BYTES = A_ROWS * 128, B_BYTES = 128 * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [A0 | A1 | B0 | B1]
+    typedef __attribute__((address_space(3))) void* lptr;
+    typedef __attribute__((address_space(1))) const void* gptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (a.M + 127) >> 7;
+    const int tile_m = blockIdx.x % ntm, tile_n = blockIdx.x / ntm;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* W = reinterpret_cast<const T*>(a.W);
+    T* Y = reinterpret_cast<T*>(a.Y);
+    const T* R = reinterpret_cast<const T*>(a.R);
+
+    if (a.lens) {
+        int mlast = min(m0 + 127, a.M - 1);
+        int b0 = m0 / a.S, b1 = mlast / a.S;
+        if (b0 == b1 && (m0 - b0 * a.S) >= a.lens[b0]) {
+            if (!a.accumulate) {
+                for (int i = tid; i < 128 * 128; i += 256) {
+                    int r = i >> 7, c = i & 127;
+                    int m = m0 + r, n = n0 + c;
+                    if (m < a.M && n < a.N) Elem<T>::st(Y + (size_t)m * a.ldy + n, 0.f);
+                }
             }
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) { v[e] *= a.out_scale; if (padrow) v[e] = 0.f; }
-            if (a.accumulate) {
-                uint4 yy = *reinterpret_cast<const uint4*>(yp);
-                if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&yy); for (int e = 0; e < 4; ++e) v[e] += f[e]; }
-                else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy); for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); } }
-            }
-            uint4 o;
-            if constexpr (sizeof(T) == 4) { float* f = reinterpret_cast<float*>(&o); for (int e = 0; e < 4; ++e) f[e] = v[e]; }
-            else { uint32_t* u = reinterpret_cast<uint32_t*>(&o); for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16); }
-            *reinterpret_cast<uint4*>(yp) = o;
-        } else {
-            for (int e = 0; e < EPT && n + e < a.N; ++e) {
-                float x = v[e];
-                if (rp) { float rv = Elem<T>::ld(rp + e); x = gate ? (rv > 0.f ? x : 0.f) : x + rv; }
-                x *= a.out_scale;
-                if (padrow) x = 0.f;
-                if (a.accumulate) x += Elem<T>::ld(yp + e);
-                Elem<T>::st(yp + e, x);
-            }
+            return;
         }
     }
+    const int nkc = (a.Cin + BK - 1) / BK;
+    const int nsteps = a.taps * nkc;
+    const T* zline = reinterpret_cast<const T*>(fs2_zero_line);
+    // DMA lane geometry: a wave-load covers 8 rows x 128 B; lane -> (row lr, linear chunk lc), source chunk lc ^ f(row)
+    const int lr = lane >> 3, lc = lane & 7;
+
+    auto load_A = [&](int kc, int buf) {            // 20 wave-loads, 5 per wave
+        unsigned char* dst = smem + buf * A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            int wl = wave * 5 + j;
+            if (wl * 8 >= 128 + (a.taps - 1) * a.dil) continue;   // wave-uniform: rows beyond the needed halo
+            int r = wl * 8 + lr;                     // halo-tile row
+            int g = m0 - a.pad + r;                  // global activation row
+            int col = kc * BK + ((lc ^ ((r >> 1) & 7)) * EPC);
+            const T* src = (g >= 0 && g < a.M && col < a.Cin) ? X + ((size_t)g * a.ldx + col) : zline;
+            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(dst + wl * 1024), 16, 0, 0);
+        }
+    };
+    auto load_B = [&](int step, int buf) {          // 16 wave-loads, 4 per wave
+        int kc = step / a.taps, tap = step - kc * a.taps;
+        unsigned char* dst = smem + 2 * A_BYTES + buf * B_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int wl = wave * 4 + j;
+            int r = wl * 8 + lr;
+            int n = n0 + r;
+            int col = kc * BK + ((lc ^ ((r >> 1) & 7)) * EPC);
+            const T* src = (n < a.N && col < a.Cin) ? W + ((size_t)n * a.ldw + (size_t)tap * a.Cin + col) : zline;
+            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(dst + wl * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fl = lane & 31, fh = lane >> 5;
+    // tap-validity bitmask of this lane's two A rows (bit j: tap j stays inside the row's sequence)
+    unsigned vmask[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        int m = m0 + wm * 64 + mb * 32 + fl;
+        unsigned msk = 0;
+        if (m < a.M) {
+            int t = m % a.S;
+            for (int j = 0; j < a.taps; ++j) {
+                int ts = t + j * a.dil - a.pad;
+                if (ts >= 0 && ts < a.S) msk |= 1u << j;
+            }
+        }
+        vmask[mb] = msk;
+    }
+    const bool need_mask = a.taps > 1;
+
+    load_A(0, 0);
+    load_B(0, 0);
+    __syncthreads();                                 // compiler drains vmcnt(0) before the barrier
+    for (int step = 0; step < nsteps; ++step) {
+        const int kc = step / a.taps, tap = step - kc * a.taps;
+        if (step + 1 < nsteps) {
+            if (tap == a.taps - 1) load_A(kc + 1, (kc + 1) & 1);
+            load_B(step + 1, (step + 1) & 1);
+        }
+        const unsigned char* As = smem + (kc & 1) * A_BYTES + tap * a.dil * 128;
+        const unsigned char* Bs = smem + 2 * A_BYTES + (step & 1) * B_BYTES;
+        const int roff = tap * a.dil;                // physical halo row = logical row + roff (swizzle uses the physical row)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 af[2], bf[2];
+            int c = fh * 4 + j;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                int r = wm * 64 + mb * 32 + fl;
+                int pr = r + roff;
+                af[mb] = *reinterpret_cast<const uint4*>(As + r * 128 + ((c ^ ((pr >> 1) & 7)) << 4));
+                if (need_mask && !((vmask[mb] >> tap) & 1u)) af[mb] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                int r = wn * 64 + nb * 32 + fl;
+                bf[nb] = *reinterpret_cast<const uint4*>(Bs + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                reinterpret_cast<const float*>(&af[mb])[jj], reinterpret_cast<const float*>(&bf[nb])[jj],
+                                acc[mb][nb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, af[mb]), __builtin_bit_cast(bf16x8, bf[nb]), acc[mb][nb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        int cl = wn * 64 + nb * 32 + fl;
+        int n = n0 + cl;
+        float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int rl = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float v = acc[mb][nb][r] + bv;
+                if (a.act != FS2_ACT_GATE) v = apply_act(v, a.act, a.slope);
+                tile[rl * 128 + cl] = v;
+            }
+    }
+    __syncthreads();
+    gemm_store_tile<T>(a, tile, m0, n0, tid);
 }
 
 extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
@@ -311,7 +496,19 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     a.slope = slope; a.in_act = in_act; a.in_slope = in_slope; a.accumulate = accumulate; a.out_scale = out_scale;
     a.vec_ok = (ldy % epc == 0) && (((uintptr_t)Y & 15) == 0) && (!R || ((ldr % epc == 0) && (((uintptr_t)R & 15) == 0)));
     long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
-    if (dtype == FS2_F32) conv_gemm_kernel<float><<<(unsigned)grid, 256, 0, stream>>>(a);
+    // taps == 1 keeps the register-staged kernel (its 3-stage pipeline wins when there is no halo to reuse)
+    const bool dma = in_act == FS2_ACT_NONE && taps > 1 && (taps - 1) * dil <= 16 && taps <= 32;
+    if (dma) {
+        const int dyn = 2 * 160 * 128 + 2 * 128 * 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            attr_set = true;
+        }
+        if (dtype == FS2_F32) conv_gemm_dma_kernel<float><<<(unsigned)grid, 256, dyn, stream>>>(a);
+        else conv_gemm_dma_kernel<bf16_t><<<(unsigned)grid, 256, dyn, stream>>>(a);
+    } else if (dtype == FS2_F32) conv_gemm_kernel<float><<<(unsigned)grid, 256, 0, stream>>>(a);
     else conv_gemm_kernel<bf16_t><<<(unsigned)grid, 256, 0, stream>>>(a);
     FS2_CHECK_LAUNCH("conv_gemm");
     return FS2_OK;
@@ -359,6 +556,7 @@ struct WgradArgs {
     const void* dY; long lddy;
     const void* X; long ldx;
     float* dW;
+    const int32_t* lens;   // optional: dY rows t >= lens[seq] are known to be zero -> their K-tiles are skipped
     int M, N, Cin, S, taps, dil, pad, rows_per_split;
 };
 
@@ -497,14 +695,17 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
     const int sr = tid >> 4, sc = tid & 15;
     const bool ncol_ok = (n0 + sc * 8) < a.N, ccol_ok = (c0 + sc * 8) < a.Cin;
     uint4 ra[4], rb[5];
+    bool live_next = true;
     auto load_tile = [&](int u) {
         int seq = u / tps, t0 = (u - seq * tps) * 64;
         size_t base = (size_t)seq * a.S;
+        const int tend = a.lens ? min(a.lens[seq], a.S) : a.S;      // rows >= tend carry zero gradient
+        live_next = t0 < tend;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int t = t0 + sr + 16 * i;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (ncol_ok && t < a.S) v = *reinterpret_cast<const uint4*>(dY + (base + t) * a.lddy + n0 + sc * 8);
+            if (ncol_ok && t < tend) v = *reinterpret_cast<const uint4*>(dY + (base + t) * a.lddy + n0 + sc * 8);
             ra[i] = v;
         }
 #pragma unroll
@@ -512,7 +713,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
             int xr = sr + 16 * i;                       // halo-tile row 0..79 (only < XROWS stored)
             int t = t0 + shift0 + xr;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (ccol_ok && xr < XROWS && t >= 0 && t < a.S) v = *reinterpret_cast<const uint4*>(X + (base + t) * a.ldx + c0 + sc * 8);
+            if (live_next && ccol_ok && xr < XROWS && t >= 0 && t < a.S) v = *reinterpret_cast<const uint4*>(X + (base + t) * a.ldx + c0 + sc * 8);
             rb[i] = v;
         }
     };
@@ -547,10 +748,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
     store_tile(0);
     __syncthreads();
     for (int u = ubeg; u < uend; ++u) {
+        const bool live = live_next;
         if (u + 1 < uend) load_tile(u + 1);
         const int buf = (u - ubeg) & 1;
         const unsigned char* As = smem + buf * (A_BYTES + X_BYTES);
         const unsigned char* Bs = As + A_BYTES;
+        if (live)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             s16x8 af[2];
@@ -621,14 +824,14 @@ static int launch_wgrad_bf16(WgradArgs a, int S_eff, hipStream_t stream) {
     return 0;
 }
 
-extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, int M, int N, int Cin, int S,
-                              int taps, int dil, int pad, int dtype, hipStream_t stream) {
+extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, const int32_t* lens, int M, int N,
+                              int Cin, int S, int taps, int dil, int pad, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(dY && X && dW, "conv_wgrad: null pointer");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0, "conv_wgrad: bad shape");
     FS2_CHECK_ARG(N % 4 == 0 && Cin % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0, "conv_wgrad: N/Cin/ld must be multiples of 4");
     if (M == 0) return FS2_OK;
     WgradArgs a;
-    a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps;
+    a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps;
     a.dil = dil; a.pad = pad;
     long tiles = (long)fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128) * taps;
     // split rows so that ~1024 workgroups exist, each covering a multiple of 32 rows (>= 256 rows).
@@ -642,7 +845,7 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) {
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
-        if (fast && taps == 1) launch_wgrad_bf16<1>(a, M, stream);            // no taps: one "sequence" of M rows
+        if (fast && taps == 1) launch_wgrad_bf16<1>(a, (lens && M % S == 0) ? S : M, stream);   // no taps, no lens: one "sequence" of M rows
         else if (fast && 2 * dil <= 8 && M % S == 0) launch_wgrad_bf16<3>(a, S, stream);
         else conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
     } else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }

@@ -22,7 +22,7 @@ struct LnArgs {
     const uint64_t* seed_dev;   // optional device-resident per-step seed offset (keeps hipGraph replays fresh)
 };
 
-template <typename T>
+template <typename T, int NV>
 __global__ void ln_fwd_kernel(LnArgs a) {
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= a.rows) return;
@@ -30,12 +30,12 @@ __global__ void ln_fwd_kernel(LnArgs a) {
     T* y = reinterpret_cast<T*>(a.y) + (size_t)row * a.C;
     const T* res = a.res ? reinterpret_cast<const T*>(a.res) + (size_t)row * a.C : nullptr;
     T* out = reinterpret_cast<T*>(a.out) + (size_t)row * a.C;
-    float4 v[FS2_LN_MAXV];
+    float4 v[NV];
     const float ik_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
     if (a.seed_dev) { uint64_t o = *a.seed_dev; a.seed_pre += o; a.seed_post += o; }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < FS2_LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = lane * 4 + i * 256;
         if (c < a.C) {
             float4 x = ld4<T>(y + c);
@@ -60,7 +60,7 @@ __global__ void ln_fwd_kernel(LnArgs a) {
     float mean = wave_sum(sum) / (float)a.C;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < FS2_LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = lane * 4 + i * 256;
         if (c < a.C) {
             float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
@@ -73,7 +73,7 @@ __global__ void ln_fwd_kernel(LnArgs a) {
     if (a.lens) { int b = row / a.S; pad = (row - b * a.S) >= a.lens[b]; }
     const float ik_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
 #pragma unroll
-    for (int i = 0; i < FS2_LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = lane * 4 + i * 256;
         if (c < a.C) {
             float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
@@ -107,8 +107,11 @@ extern "C" int fs2_ln_fwd(void* y, const void* res, const float* gamma, const fl
     a.rows = B * S; a.S = S; a.C = C; a.eps = eps; a.p_pre = p_pre; a.p_post = p_post; a.seed_pre = seed_pre; a.seed_post = seed_post;
     a.seed_dev = seed_dev;
     if (a.rows == 0) return FS2_OK;
-    if (dtype == FS2_F32) ln_fwd_kernel<float><<<fs2_cdiv(a.rows, 4), 256, 0, stream>>>(a);
-    else if (dtype == FS2_BF16) ln_fwd_kernel<bf16_t><<<fs2_cdiv(a.rows, 4), 256, 0, stream>>>(a);
+    const int nv = C <= 256 ? 1 : (C <= 512 ? 2 : (C <= 1024 ? 4 : 8));
+#define LN_FWD_LAUNCH(TT, NVV) ln_fwd_kernel<TT, NVV><<<fs2_cdiv(a.rows, 4), 256, 0, stream>>>(a)
+#define LN_FWD_NV(TT) do { if (nv == 1) LN_FWD_LAUNCH(TT, 1); else if (nv == 2) LN_FWD_LAUNCH(TT, 2); else if (nv == 4) LN_FWD_LAUNCH(TT, 4); else LN_FWD_LAUNCH(TT, 8); } while (0)
+    if (dtype == FS2_F32) LN_FWD_NV(float);
+    else if (dtype == FS2_BF16) LN_FWD_NV(bf16_t);
     else { fs2_set_error("ln_fwd: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("ln_fwd");
     return FS2_OK;
@@ -132,26 +135,26 @@ struct LnBwdArgs {
     int relu_bwd;
 };
 
-template <typename T>
-__global__ void ln_bwd_kernel(LnBwdArgs a) {
-    __shared__ float s_red[4][64 * 4];
+template <typename T, int NV>
+__global__ void __launch_bounds__(512) ln_bwd_kernel(LnBwdArgs a) {
+    __shared__ float s_red[8][64 * 4];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float4 ag[FS2_LN_MAXV], ab[FS2_LN_MAXV];
+    float4 ag[NV], ab[NV];
 #pragma unroll
-    for (int i = 0; i < FS2_LN_MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+    for (int i = 0; i < NV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
     const float ik_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
     const float ik_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
     if (a.seed_dev) { uint64_t o = *a.seed_dev; a.seed_pre += o; a.seed_post += o; }
-    for (int row = blockIdx.x * 4 + w; row < a.rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * 8 + w; row < a.rows; row += gridDim.x * 8) {
         bool pad = false;
         if (a.lens) { int b = row / a.S; pad = (row - b * a.S) >= a.lens[b]; }
         const T* z = reinterpret_cast<const T*>(a.z) + (size_t)row * a.C;
         const T* dout = reinterpret_cast<const T*>(a.dout) + (size_t)row * a.C;
         float mean = a.mean[row], rstd = a.rstd[row];
-        float4 xh[FS2_LN_MAXV], gg[FS2_LN_MAXV];
+        float4 xh[NV], gg[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < FS2_LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             int c = lane * 4 + i * 256;
             if (c < a.C) {
                 float4 zz = ld4<T>(z + c);
@@ -178,7 +181,7 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
         s1 = wave_sum(s1) / (float)a.C;
         s2 = wave_sum(s2) / (float)a.C;
 #pragma unroll
-        for (int i = 0; i < FS2_LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             int c = lane * 4 + i * 256;
             if (c < a.C) {
                 float4 dz;
@@ -218,7 +221,7 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
     // block reduction of dgamma / dbeta partials: 4 waves -> LDS -> wave 0 -> partial[block][2][C]
     // (a second tiny kernel sums the per-block partials: no same-address atomic storm)
 #pragma unroll
-    for (int i = 0; i < FS2_LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         int c = lane * 4 + i * 256;
         if (c >= a.C) break;   // uniform across waves for a given i
         __syncthreads();
@@ -226,7 +229,7 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
         __syncthreads();
         if (w == 0) {
             float4 t = ag[i];
-            for (int k = 1; k < 4; ++k) { float4 o = *reinterpret_cast<float4*>(&s_red[k][lane * 4]); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            for (int k = 1; k < 8; ++k) { float4 o = *reinterpret_cast<float4*>(&s_red[k][lane * 4]); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
             *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.x * 2) * a.C + c) = t;
         }
         __syncthreads();
@@ -234,7 +237,7 @@ __global__ void ln_bwd_kernel(LnBwdArgs a) {
         __syncthreads();
         if (w == 0) {
             float4 t = ab[i];
-            for (int k = 1; k < 4; ++k) { float4 o = *reinterpret_cast<float4*>(&s_red[k][lane * 4]); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            for (int k = 1; k < 8; ++k) { float4 o = *reinterpret_cast<float4*>(&s_red[k][lane * 4]); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
             *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.x * 2 + 1) * a.C + c) = t;
         }
     }
@@ -273,10 +276,13 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     FS2_CHECK_ARG(partial_ws, "ln_bwd: partial_ws (FS2_LN_BWD_GRID*2*C floats) is required");
     a.partial = partial_ws;
     if (a.rows == 0) return FS2_OK;
-    int grid = fs2_cdiv(a.rows, 4);
+    int grid = fs2_cdiv(a.rows, 8);
     if (grid > FS2_LN_BWD_GRID) grid = FS2_LN_BWD_GRID;
-    if (dtype == FS2_F32) ln_bwd_kernel<float><<<grid, 256, 0, stream>>>(a);
-    else if (dtype == FS2_BF16) ln_bwd_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
+    const int nv = C <= 256 ? 1 : (C <= 512 ? 2 : (C <= 1024 ? 4 : 8));
+#define LN_BWD_LAUNCH(TT, NVV) ln_bwd_kernel<TT, NVV><<<grid, 512, 0, stream>>>(a)
+#define LN_BWD_NV(TT) do { if (nv == 1) LN_BWD_LAUNCH(TT, 1); else if (nv == 2) LN_BWD_LAUNCH(TT, 2); else if (nv == 4) LN_BWD_LAUNCH(TT, 4); else LN_BWD_LAUNCH(TT, 8); } while (0)
+    if (dtype == FS2_F32) LN_BWD_NV(float);
+    else if (dtype == FS2_BF16) LN_BWD_NV(bf16_t);
     else { fs2_set_error("ln_bwd: dtype"); return FS2_EDTYPE; }
     ln_bwd_reduce_kernel<<<fs2_cdiv(2 * C, 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
     FS2_CHECK_LAUNCH("ln_bwd");

@@ -133,29 +133,30 @@ class Engine:
         wf, _, b, shape = W[key]
         return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res)
 
-    def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None):
+    def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None, lens=None):
         """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
         _, wd, _, shape = W[key]
-        return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res)
+        return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens)
 
-    def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0):
+    def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0, lens=None):
         if gw.dim() == 3:
             gw = gw.permute(0, 2, 1)            # tap-major storage of the gradient
-        ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad)
+        ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens)
         ops.colsum(dy, gb)
 
     def _fft_fwd(self, W, pre, x, lens, B, S, n_head, p, seed_dev, site, keep):
         ks = self.tc["conv_kernel_size"]
         a, f = pre + "slf_attn.", pre + "pos_ffn."
         sv = _Saved()
-        qkv = self._gemm(W, a + "qkv", x, S)
+        # padded rows are never consumed downstream (keys masked, LN output re-masked): their tiles are skipped
+        qkv = self._gemm(W, a + "qkv", x, S, lens=lens)
         ctx, lse = ops.attn_fwd(qkv, lens, B, S, n_head, self.d // n_head)
-        y1 = self._gemm(W, a + "fc", ctx, S)
+        y1 = self._gemm(W, a + "fc", ctx, S, lens=lens)
         h, mean1, rstd1 = ops.ln_fwd(y1, x, self.P[a + "layer_norm.weight"], self.P[a + "layer_norm.bias"], lens, B, S,
                                      p_pre=p, seed_pre=_site_seed(site), seed_dev=seed_dev)
         hid = self._gemm(W, f + "w_1", h, S, taps=ks[0], pad=(ks[0] - 1) // 2, act=ACT_RELU,
                          lens=lens if ks[1] == 1 else None)
-        y2 = self._gemm(W, f + "w_2", hid, S, taps=ks[1], pad=(ks[1] - 1) // 2)
+        y2 = self._gemm(W, f + "w_2", hid, S, taps=ks[1], pad=(ks[1] - 1) // 2, lens=lens if ks[1] == 1 else None)
         out, mean2, rstd2 = ops.ln_fwd(y2, h, self.P[f + "layer_norm.weight"], self.P[f + "layer_norm.bias"], lens, B, S,
                                        p_pre=p, seed_pre=_site_seed(site + 1), seed_dev=seed_dev)
         if keep:
@@ -173,19 +174,21 @@ class Engine:
                               p_pre=p, seed_pre=_site_seed(sv.site + 1), seed_dev=seed_dev)
         if dy2 is None:
             dy2 = dz2
-        self._wgrad(G[f + "w_2.weight"], G[f + "w_2.bias"], dy2, sv.hid, S, taps=ks[1], pad=(ks[1] - 1) // 2)
-        dhid = self._dgemm(W, f + "w_2", dy2, S, taps=ks[1], pad=(ks[1] - 1) // 2, act=ACT_GATE, res=sv.hid)
-        self._wgrad(G[f + "w_1.weight"], G[f + "w_1.bias"], dhid, sv.h, S, taps=ks[0], pad=(ks[0] - 1) // 2)
-        dh = self._dgemm(W, f + "w_1", dhid, S, taps=ks[0], pad=(ks[0] - 1) // 2, res=dz2)
+        # all gradients below are zero on padded rows (ln_bwd zeroes them) -> lens lets every kernel skip those tiles
+        l2 = lens if ks[1] == 1 else None
+        self._wgrad(G[f + "w_2.weight"], G[f + "w_2.bias"], dy2, sv.hid, S, taps=ks[1], pad=(ks[1] - 1) // 2, lens=lens)
+        dhid = self._dgemm(W, f + "w_2", dy2, S, taps=ks[1], pad=(ks[1] - 1) // 2, act=ACT_GATE, res=sv.hid, lens=l2)
+        self._wgrad(G[f + "w_1.weight"], G[f + "w_1.bias"], dhid, sv.h, S, taps=ks[0], pad=(ks[0] - 1) // 2, lens=l2)
+        dh = self._dgemm(W, f + "w_1", dhid, S, taps=ks[0], pad=(ks[0] - 1) // 2, res=dz2, lens=lens)
         dz1, dy1 = ops.ln_bwd(sv.z1, dh, self.P[a + "layer_norm.weight"], lens, sv.mean1, sv.rstd1,
                               G[a + "layer_norm.weight"], G[a + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
                               p_pre=p, seed_pre=_site_seed(sv.site), seed_dev=seed_dev)
         if dy1 is None:
             dy1 = dz1
-        self._wgrad(G[a + "fc.weight"], G[a + "fc.bias"], dy1, sv.ctx, S)
-        dctx = self._dgemm(W, a + "fc", dy1, S)
+        self._wgrad(G[a + "fc.weight"], G[a + "fc.bias"], dy1, sv.ctx, S, lens=lens)
+        dctx = self._dgemm(W, a + "fc", dy1, S, lens=lens)
         dqkv = ops.attn_bwd(sv.qkv, sv.ctx, dctx, sv.lse, lens, B, S, n_head, self.d // n_head)
-        self._wgrad(G[a + "qkv.weight"], G[a + "qkv.bias"], dqkv, sv.x, S)
+        self._wgrad(G[a + "qkv.weight"], G[a + "qkv.bias"], dqkv, sv.x, S, lens=lens)
         return self._dgemm(W, a + "qkv", dqkv, S, res=dz1)
 
     def _pred_fwd(self, W, kind, x, lens, B, S, p, seed_dev, site, keep):

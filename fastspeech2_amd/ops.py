@@ -92,11 +92,11 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     return out
 
 
-def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0):
+def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None):
     """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x."""
     M, N = dy.shape
     Cin = x.shape[1]
-    _lib.call("fs2_conv_wgrad", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), M, N, Cin, S, taps, dil, pad, dt(dy),
+    _lib.call("fs2_conv_wgrad", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(lens), M, N, Cin, S, taps, dil, pad, dt(dy),
               _stream())
 
 
