@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/fs2hip.h declares (no compute
+calls); argument validation returns the documented error codes before any launch."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from fastspeech2_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    protos = _lib.parse_header()
+    assert len(protos) >= 33
+    for name in protos:
+        assert hasattr(lib, name), name
+    # and nothing the header promises is missing from the dynamic symbol table
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r"\b(fs2_\w+)\b", out))
+    assert set(protos) <= exported
+    # every exported fs2_* entry point is declared (no undocumented ABI)
+    undeclared = {s for s in exported if not s.startswith("fs2_set_error")} - set(protos)
+    assert not undeclared, undeclared
+
+
+def test_version_and_error_string():
+    lib = _lib.load()
+    assert lib.fs2_version() >= 100
+    assert isinstance(lib.fs2_last_error(), bytes)
+
+
+def test_bad_arguments_are_rejected_before_launch():
+    """FS2_EINVAL (-1) -> ValueError, FS2_EDTYPE (-2) -> TypeError: mirrors the reference's assert/ValueError style."""
+    with pytest.raises(ValueError):
+        _lib.call("fs2_conv_gemm", None, 0, None, None, None, 0, None, 0, None, 0, 0, 0, 0, 1, 1, 0, 0, 0.0, 0, 0.0, 0, 1.0,
+                  0, None)
+    with pytest.raises((TypeError, ValueError)):
+        _lib.call("fs2_cast", None, 7, None, 9, 16, None)
+
+
+def test_header_is_plain_c():
+    """include/fs2hip.h must compile as C (extern "C" boundary, no C++/torch types)."""
+    src = '#include "fs2hip.h"\nint main(void){return fs2_version()>0?0:1;}\n'
+    p = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                       input=src, text=True, capture_output=True)
+    assert p.returncode == 0, p.stderr
+
+
+def test_product_forward_refuses_cpu_tensors():
+    import torch
+    from tests.golden import configs
+    from fastspeech2_amd.model import FastSpeech2
+
+    pcfg, mcfg = configs.make(dec_layers=1, enc_layers=1)
+    m = FastSpeech2(pcfg, mcfg)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, dtype=torch.long), torch.ones(1, 4, dtype=torch.long), torch.tensor([4]), 4)

@@ -1,0 +1,68 @@
+"""CPU: host-side logic above the C ABI that needs no kernel launch — LR schedule, flat parameter layout,
+checkpoint (state_dict) round trip, tap-major weight views."""
+import torch
+
+from oracle import fs2_oracle as O
+from tests.golden import configs
+from tests.helpers import make_model
+from fastspeech2_amd.model import ScheduledOptim
+
+
+def test_lr_schedule_matches_oracle():
+    """reference model/optimizer.py:33-51: current_step increments before the lr is computed."""
+    pcfg, mcfg = configs.make(dec_layers=1, enc_layers=1)
+    opt = ScheduledOptim(make_model(pcfg, mcfg), configs.TRAIN, mcfg, 0)
+    oc = configs.TRAIN["optimizer"]
+    for step in (1, 2, 100, 3999, 4000, 4001, 299999, 300000, 300001, 400001, 500001, 900000):
+        opt.current_step = step
+        got = opt.init_lr * opt._get_lr_scale()
+        want = O.lr_at_step(step, 256, oc["warm_up_step"], oc["anneal_steps"], oc["anneal_rate"])
+        assert abs(got - want) <= 1e-12 + 1e-9 * want, step
+
+
+def test_flat_layout_aliases_every_trainable_parameter():
+    pcfg, mcfg = configs.make(dec_layers=2, enc_layers=1, multi_speaker=True)
+    m = make_model(pcfg, mcfg)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m._ensure_flat(torch.device("cpu"))
+    after = m.state_dict()
+    assert list(before) == list(after)
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
+    flat = m.flat_parameters()
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    n = 0
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            assert lo <= p.data_ptr() < hi, name
+            n += p.numel()
+    assert n <= flat.numel() < n + 4 * len(list(m.parameters()))
+    # conv weights are stored tap-major: the (Cout, Cin, k) parameter is a permuted view of [Cout][k][Cin]
+    w = m.encoder.layer_stack[0].pos_ffn.w_1.weight
+    assert w.shape == (1024, 256, 9) and w.stride() == (9 * 256, 1, 256)
+    # QKV weights are adjacent so the fused [3d, d] projection is one matrix
+    a = m.decoder.layer_stack[1].slf_attn
+    assert a.w_ks.weight.data_ptr() == a.w_qs.weight.data_ptr() + 256 * 256 * 4
+    assert a.w_vs.weight.data_ptr() == a.w_ks.weight.data_ptr() + 256 * 256 * 4
+    # writing through a parameter is visible in the flat buffer (optimizer/engine see the same memory)
+    with torch.no_grad():
+        m.mel_linear.bias.fill_(3.5)
+    o = m._flat_offsets["mel_linear.bias"]
+    assert torch.all(flat[o:o + 80] == 3.5)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """train.py:152-161 format {"model": sd, "optimizer": sd}: model keys load into a fresh module unchanged."""
+    pcfg, mcfg = configs.make(dec_layers=1, enc_layers=1)
+    m1 = make_model(pcfg, mcfg)
+    m1._ensure_flat(torch.device("cpu"))
+    path = tmp_path / "10.pth.tar"
+    torch.save({"model": m1.state_dict()}, path)
+    m2 = make_model(pcfg, mcfg)
+    m2._ensure_flat(torch.device("cpu"))
+    m2.load_state_dict(torch.load(path)["model"])
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    # loading must keep the parameters aliased to the flat buffer
+    flat = m2.flat_parameters()
+    assert flat.data_ptr() <= m2.mel_linear.weight.data_ptr() < flat.data_ptr() + flat.numel() * 4
