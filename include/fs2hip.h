@@ -131,6 +131,29 @@ int fs2_add(const void* a, const void* b, void* out, size_t n, int dtype, fs2_st
 int fs2_add_pe(void* x, const float* pe, int B, int S, int C, int dtype, fs2_stream_t stream);
 int fs2_bump_counter(uint64_t* ctr, uint64_t inc, fs2_stream_t stream);
 
+/* ---- vocoder (hifigan/models.py:113-174, utils/model.py:74-92) and mel extraction (audio/stft.py) ---- */
+/* The dense layers run in fs2_conv_gemm:
+ *   conv_pre / ResBlock convs   taps=k, dil, in_act = leaky_relu(0.1), residual / accumulate / out_scale=1/3 epilogue
+ *                               (models.py:96-103,150,155-160);
+ *   ConvTranspose1d(k=2u, stride u, pad u/2) as its polyphase form: a 3-tap conv with N = u*Cout whose output rows
+ *                               [B*T][u*Cout] ARE the up-sampled time-major rows [B*T*u][Cout] (models.py:124-135,152-153);
+ *   framed DFT                  X = reflect-padded wav viewed as rows [B*rows][hop], taps = filter/hop (stft.py:66-72).
+ * (B, C, T) float32 -> rows [B*T][C] in `dtype` (vocoder_infer receives mels channel-major, utils/model.py:74-80). */
+int fs2_chan_to_rows(const float* in, void* out, int B, int C, int T, int dtype, fs2_stream_t stream);
+/* models.py:161-163 + utils/model.py:82-85: y = tanh(conv(leaky_relu(x, in_slope), w[taps][C]) + bias);
+ * wav[m] = y (optional), pcm[m] = (int16)(y * max_wav_value) with numpy's astype semantics (optional). */
+int fs2_conv_post_pcm(const void* x, long ldx, const float* w, const float* bias, float in_slope, float* wav,
+                      int16_t* pcm, float max_wav_value, int M, int S, int C, int taps, int pad, int dtype,
+                      fs2_stream_t stream);
+/* stft.py:60-66: xp[b][i] = y[b][reflect(i - P)], i < N + 2P; zero-filled up to row_len. */
+int fs2_reflect_pad(const float* y, float* xp, int B, int N, int P, long row_len, fs2_stream_t stream);
+/* stft.py:74-78,174-176 + audio_processing.py:91: ft rows [B*S][2*NF] (Re|Im) -> mel (B, n_mel, frames) =
+ * log(clamp(mel_basis[n_mel][NF] . |ft|, clamp_min)), energy (B, frames) = ||ft|||_2; span[n_mel][2] = non-zero
+ * band [lo, hi) of each filter. */
+int fs2_stft_mel_epilogue(const float* ft, long ldft, const float* mel_basis, const int32_t* span, float* mel,
+                          float* energy, int B, int S, int frames, int NF, int n_mel, float clamp_min,
+                          fs2_stream_t stream);
+
 /* ---- optimiser: train.py:93 clip_grad_norm_ + model/optimizer.py:10-51 Adam ------------------------- */
 int fs2_sumsq(const float* x, size_t n, float* out /*+=*/, fs2_stream_t stream);
 /* hyper (device) = {lr, 1-beta1^t, 1-beta2^t}; clip = min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) */

@@ -164,6 +164,49 @@ def case_hifigan(seed=11):
     print("hifigan wav rms", float(wav.pow(2).mean().sqrt()), wav.shape)
 
 
+def case_stft():
+    """The reference's own audio/stft.py TacotronSTFT on CPU.  librosa (absent here) is stubbed: pad_center / tiny are
+    trivial; filters.mel serves the ORACLE's restated Slaney filterbank (so the filterbank itself stays "parity
+    unpinned"; everything else — DFT basis, window, reflect pad, framing, magnitude, mel matmul, log-clamp, energy —
+    is the reference's code).  `.cuda()` is neutralised (stft.py:68-69 call it unconditionally)."""
+    from oracle import fs2_oracle as O
+    lib = types.ModuleType("librosa")
+    util = types.ModuleType("librosa.util")
+    filt = types.ModuleType("librosa.filters")
+
+    def pad_center(data, size, axis=-1):
+        n = data.shape[axis]
+        lpad = (size - n) // 2
+        return np.pad(data, (lpad, size - n - lpad))
+    util.pad_center = pad_center
+    util.tiny = lambda x: np.finfo(np.float32).tiny
+    util.normalize = lambda x, norm=None: x
+    filt.mel = lambda sr, n_fft, n_mels, fmin, fmax: O.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    lib.util, lib.filters = util, filt
+    sys.modules.update({"librosa": lib, "librosa.util": util, "librosa.filters": filt})
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        from audio.stft import TacotronSTFT
+        from scipy.io import wavfile
+        stft = TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000)
+        sr, wav = wavfile.read(os.path.join(REF, "demo", "LJSpeech", "LJ001-0012_ground-truth.wav"))
+        assert sr == 22050
+        real = (wav[20000:20000 + 7 * 256 + 100].astype(np.float32) / 32768.0)
+        g = torch.Generator().manual_seed(21)
+        n = real.shape[0]
+        tt = torch.arange(n, dtype=torch.float32) / 22050.0
+        synth = 0.4 * torch.sin(2 * np.pi * 440.0 * tt) + 0.2 * torch.sin(2 * np.pi * 3000.0 * tt) + 0.05 * torch.randn(n, generator=g)
+        y = torch.stack([torch.from_numpy(real), torch.clamp(synth, -1, 1)])
+        mel, energy = stft.mel_spectrogram(y)
+        mag, _ = stft.stft_fn.transform(y)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(HERE, "stft.npz"), y=y.numpy(), mel=mel.numpy(), energy=energy.numpy(),
+                        mag_sample=mag[:, ::37, :].numpy(), forward_basis_rows=stft.stft_fn.forward_basis[::101, 0, :].numpy())
+    print("stft mel", tuple(mel.shape), float(mel.min()), float(mel.max()), "energy max", float(energy.max()))
+
+
 if __name__ == "__main__":
     os.chdir(REF)
     case_length_regulator()
@@ -173,3 +216,4 @@ if __name__ == "__main__":
     case_eval("eval_lj", 4321, B=3, L=20, controls=(1.2, 0.9, 1.1))
     case_eval("eval_multi", 55, B=2, L=12, controls=(1.0, 1.0, 0.8), multi_speaker=True, dec_layers=2, enc_layers=2)
     case_hifigan()
+    case_stft()

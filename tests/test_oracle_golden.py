@@ -133,3 +133,21 @@ def hifigan_shapes(h=configs.HIFIGAN):
                 conv(f"resblocks.{i * nk + j}.convs2.{m}", ch, ch, rk)
     conv("conv_post", 1, ch, 7)
     return s
+
+
+def test_oracle_stft_matches_reference():
+    """audio/stft.py run live (tests/golden/make_golden.py:case_stft) vs the oracle's restatement.  The mel
+    filterbank in BOTH is the restated Slaney formula (librosa absent): that boundary is parity-unpinned."""
+    g = load_golden("stft")
+    y = torch.from_numpy(g["y"])
+    mel, energy = O.mel_spectrogram(y)
+    assert mel.shape == g["mel"].shape and energy.shape == g["energy"].shape
+    assert (mel - torch.from_numpy(g["mel"])).abs().max().item() < 1e-4
+    assert np.allclose(energy.numpy(), g["energy"], rtol=1e-5, atol=1e-5)
+    basis = O.stft_basis(1024, 1024)
+    assert np.array_equal(basis[::101].numpy(), g["forward_basis_rows"])       # windowed DFT basis: bit-exact
+
+
+def test_oracle_pcm16_matches_numpy_cast():
+    wav = torch.tensor([0.0, 0.5, -0.5, 0.99999, -1.0, 1.0 / 32768.0 * 2.9, -1.0 / 32768.0 * 2.9])
+    assert O.pcm16(wav).tolist() == [0, 16384, -16384, 32767, -32768, 2, -2]
