@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--phonemes", type=int, default=128)
     ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (1 GPU)")
+    ap.add_argument("--mode", default="train", choices=["train", "synth"],
+                    help="train: mel-frames/s of the train step (default, the driver's metric); synth: batch-synthesis RTF")
+    ap.add_argument("--synth-batch", type=int, default=8, help="utterances per synthesis batch (synthesize.py:199 uses 8)")
+    ap.add_argument("--vocoder-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -120,8 +124,83 @@ def cpu_baseline(args):
                       f"host cpu_count={os.cpu_count()}"}
 
 
+def synth_main(args):
+    """BASELINE metric part 2: batch-synthesis real-time factor = wall(acoustic model + HiFi-GAN + int16) / audio seconds
+    on LJSpeech-shaped synthetic text batches (random-init weights; duration-predictor bias set so that ~7 frames per
+    phoneme are produced).  One process per GPU, replicas only (no collective)."""
+    import math
+    from tests.golden import configs
+    from oracle.weights import synthetic_batch
+    from fastspeech2_amd.model import FastSpeech2
+    from fastspeech2_amd import hifigan, utils
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
+    torch.manual_seed(1234)
+    model = FastSpeech2(pcfg, mcfg, compute_dtype=args.dtype)
+    with torch.no_grad():
+        model.variance_adaptor.duration_predictor.linear_layer.bias.fill_(math.log(8.0))
+    model.to(device).eval()
+    voc = hifigan.Generator(hifigan.AttrDict(utils.HIFIGAN_V1), compute_dtype=args.vocoder_dtype)
+    voc.eval()
+    voc.remove_weight_norm()
+    voc.to(device)
+    B = args.synth_batch
+    b = synthetic_batch(4321 + rank, B, args.phonemes, min_len_frac=0.5)
+    batch = ([f"u{i}" for i in range(B)], None, b["speakers"].to(device), b["texts"].to(device), b["src_lens"].to(device),
+             b["max_src_len"])
+
+    def step():
+        with torch.no_grad():
+            out = model(*batch[2:])
+            wavs = utils.synth_samples(batch, out, voc, mcfg, pcfg, None, write=False)   # includes the D2H of the PCM
+        return out, wavs
+
+    for _ in range(args.warmup):
+        out, wavs = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, wavs = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    audio_s = sum(len(w) for w in wavs) / 22050.0 * args.steps
+    tt = torch.tensor([dt, audio_s, float(out[9].sum().item()) * args.steps], device=device, dtype=torch.float64)
+    if world > 1:
+        tmax = tt[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt)
+        tt[0] = tmax[0]
+    if rank == 0:
+        dt, audio_s, frames = tt.tolist()
+        print(json.dumps({
+            "metric": "batch-synth real-time factor (acoustic model + HiFi-GAN + int16, 22.05 kHz)", "value": round(dt / audio_s, 6),
+            "unit": "s wall per s audio", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": f"{args.dtype} acoustic / {args.vocoder_dtype} vocoder", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: batch synthesis, {B} utterances/batch, L<={args.phonemes} phonemes, "
+                                   f"~7 frames/phoneme, 4+4 FastSpeech2 + HiFi-GAN V1, PCM copied to host",
+                       "audio_s_per_step": round(audio_s / args.steps, 2), "mel_frames_per_s": round(frames / dt, 1),
+                       "x_realtime": round(audio_s / dt, 1)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "synth":
+        return synth_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,0 +1,144 @@
+"""Factories and batch plumbing with the reference's names and conventions (utils/model.py, utils/tools.py).
+
+get_model / get_vocoder / vocoder_infer / to_device / get_mask_from_lengths / pad_1D / pad_2D are what train.py,
+evaluate.py and synthesize.py call around the hot path; only the device work differs (HIP kernels behind the C ABI,
+PCM conversion fused into the vocoder's last kernel).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import hifigan
+from .model import FastSpeech2, ScheduledOptim
+
+# hifigan/config.json of the reference (HiFi-GAN V1) — used when no config file sits next to the checkpoint
+HIFIGAN_V1 = {"resblock": "1", "upsample_rates": [8, 8, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4],
+              "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
+              "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "num_mels": 80, "sampling_rate": 22050,
+              "hop_size": 256, "win_size": 1024, "n_fft": 1024, "fmin": 0, "fmax": 8000}
+
+
+def get_model(args, configs, device, train=False, compute_dtype=None):
+    """utils/model.py:11-34."""
+    preprocess_config, model_config, train_config = configs
+    model = FastSpeech2(preprocess_config, model_config, compute_dtype=compute_dtype).to(device)
+    ckpt = None
+    if args.restore_step:
+        ckpt_path = os.path.join(train_config["path"]["ckpt_path"], "{}.pth.tar".format(args.restore_step))
+        ckpt = torch.load(ckpt_path, map_location="cpu")
+        model.load_state_dict(ckpt["model"])
+    if train:
+        scheduled_optim = ScheduledOptim(model, train_config, model_config, args.restore_step)
+        if args.restore_step:
+            scheduled_optim.load_state_dict(ckpt["optimizer"])
+        model.train()
+        return model, scheduled_optim
+    model.eval()
+    model.requires_grad_ = False                 # attribute assignment in the reference too (utils/model.py:33)
+    return model
+
+
+def get_param_num(model):
+    return sum(param.numel() for param in model.parameters())
+
+
+def get_vocoder(config, device, hifigan_dir="hifigan", compute_dtype="fp32", allow_random_init=False):
+    """utils/model.py:42-71 (HiFi-GAN branch; MelGAN is a torch.hub download and out of scope)."""
+    name = config["vocoder"]["model"]
+    speaker = config["vocoder"]["speaker"]
+    if name != "HiFi-GAN":
+        raise NotImplementedError(f"vocoder {name!r}: only HiFi-GAN is built (MelGAN needs torch.hub / network)")
+    cfg_path = os.path.join(hifigan_dir, "config.json")
+    if os.path.exists(cfg_path):
+        with open(cfg_path, "r") as f:
+            h = json.load(f)
+    else:
+        h = dict(HIFIGAN_V1)
+    vocoder = hifigan.Generator(hifigan.AttrDict(h), compute_dtype=compute_dtype)
+    ckpt_path = os.path.join(hifigan_dir, {"LJSpeech": "generator_LJSpeech.pth.tar",
+                                           "universal": "generator_universal.pth.tar"}[speaker])
+    if os.path.exists(ckpt_path):
+        ckpt = torch.load(ckpt_path, map_location="cpu")
+        vocoder.load_state_dict(ckpt["generator"])
+    elif not allow_random_init:
+        raise FileNotFoundError(ckpt_path)
+    vocoder.eval()
+    vocoder.remove_weight_norm()
+    vocoder.to(device)
+    return vocoder
+
+
+def vocoder_infer(mels, vocoder, model_config, preprocess_config, lengths=None):
+    """utils/model.py:74-92: mels (B, 80, T) -> list of int16 numpy arrays (cut to `lengths` samples)."""
+    name = model_config["vocoder"]["model"]
+    assert name == "HiFi-GAN"
+    with torch.no_grad():
+        pcm = vocoder.infer_pcm(mels, preprocess_config["preprocessing"]["audio"]["max_wav_value"])
+    wavs = [w for w in pcm.cpu().numpy()]
+    for i in range(len(mels)):
+        if lengths is not None:
+            wavs[i] = wavs[i][: lengths[i]]
+    return wavs
+
+
+def to_device(data, device):
+    """utils/tools.py:18-66: numpy batch tuple (12 = train, 6 = synth) -> device tensors; non_blocking from pinned
+    staging would be the data-pipeline row (§8(f) #1)."""
+    if len(data) == 12:
+        ids, raw_texts, speakers, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, pitches, energies, durations = data
+        return (ids, raw_texts,
+                torch.from_numpy(speakers).long().to(device), torch.from_numpy(texts).long().to(device),
+                torch.from_numpy(src_lens).to(device), max_src_len,
+                torch.from_numpy(mels).float().to(device), torch.from_numpy(mel_lens).to(device), max_mel_len,
+                torch.from_numpy(pitches).float().to(device), torch.from_numpy(energies).to(device),
+                torch.from_numpy(durations).long().to(device))
+    if len(data) == 6:
+        ids, raw_texts, speakers, texts, src_lens, max_src_len = data
+        return (ids, raw_texts, torch.from_numpy(speakers).long().to(device), torch.from_numpy(texts).long().to(device),
+                torch.from_numpy(src_lens).to(device), max_src_len)
+    raise ValueError(f"to_device: batch of length {len(data)} (expected 12 or 6)")
+
+
+def get_mask_from_lengths(lengths, max_len=None):
+    """utils/tools.py:91-99 — True = padding."""
+    batch_size = lengths.shape[0]
+    if max_len is None:
+        max_len = torch.max(lengths).item()
+    ids = torch.arange(0, max_len, device=lengths.device).unsqueeze(0).expand(batch_size, -1)
+    return ids >= lengths.unsqueeze(1).expand(-1, max_len)
+
+
+def pad_1D(inputs, PAD=0):
+    """utils/tools.py:265-275."""
+    max_len = max(len(x) for x in inputs)
+    return np.stack([np.pad(x, (0, max_len - x.shape[0]), mode="constant", constant_values=PAD) for x in inputs])
+
+
+def pad_2D(inputs, maxlen=None):
+    """utils/tools.py:278-296."""
+    def pad(x, max_len):
+        if np.shape(x)[0] > max_len:
+            raise ValueError("not max_len")
+        return np.pad(x, ((0, max_len - np.shape(x)[0]), (0, 0)), mode="constant", constant_values=0)
+
+    max_len = maxlen if maxlen else max(np.shape(x)[0] for x in inputs)
+    return np.stack([pad(x, max_len) for x in inputs])
+
+
+def synth_samples(targets, predictions, vocoder, model_config, preprocess_config, path, write=True):
+    """utils/tools.py:164-198 without the matplotlib figures: vocode the post-net mels of a synth batch and write
+    `{path}/{basename}.wav`.  Returns the list of int16 arrays."""
+    from scipy.io import wavfile
+
+    basenames = targets[0]
+    mel_predictions = predictions[1].transpose(1, 2)                     # (B, 80, T) view — zero-copy into the vocoder
+    lengths = predictions[9] * preprocess_config["preprocessing"]["stft"]["hop_length"]
+    wavs = vocoder_infer(mel_predictions, vocoder, model_config, preprocess_config, lengths=lengths.tolist())
+    if write:
+        os.makedirs(path, exist_ok=True)
+        sr = preprocess_config["preprocessing"]["audio"]["sampling_rate"]
+        for wav, basename in zip(wavs, basenames):
+            wavfile.write(os.path.join(path, "{}.wav".format(basename)), sr, wav)
+    return wavs
