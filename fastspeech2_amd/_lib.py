@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: torch bundles its own libamdhip6
 #                          libfs2hip.so bind to that SAME HIP runtime (two runtimes in one process cannot share streams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfs2hip.so")
+LIB_PATH = os.environ.get("FS2_LIB_PATH") or os.path.join(_HERE, "libfs2hip.so")   # FS2_LIB_PATH: dev builds (make prof)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fs2hip.h")
 
 _CTYPES = {

@@ -19,6 +19,7 @@
 // Register-staged double buffering: global loads of K-tile t+1 are issued before the MFMAs of tile t and
 // written to the other LDS buffer afterwards (one barrier per K-tile).
 #include "fs2_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -71,24 +72,24 @@ __device__ __forceinline__ uint4 act_chunk_bf16(uint4 v, float slope) {
 
 // final stage of the epilogue (shared by both GEMM kernels): the f32 tile staged in LDS is written out in whole
 // 16-byte row segments; residual / ReLU-gate operand and the accumulate operand are read the same way.
-template <typename T>
+template <typename T, int TW = 128, int NT = 256>
 __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const float* tile, int m0, int n0, int tid) {
     constexpr int EPC = MmaTraits<T>::EPC;
     T* Y = reinterpret_cast<T*>(a.Y);
     const T* R = reinterpret_cast<const T*>(a.R);
     constexpr int EPT = EPC;                 // elements per 16-byte global store
-    constexpr int CPR = 128 / EPT;           // 16-byte chunks per tile row
+    constexpr int CPR = TW / EPT;            // 16-byte chunks per tile row ([128][TW] f32 tile, NT threads)
     const bool gate = a.act == FS2_ACT_GATE;
 #pragma unroll 4
-    for (int it = 0; it < (128 * CPR) / 256; ++it) {
-        int idx = tid + 256 * it;
+    for (int it = 0; it < (128 * CPR) / NT; ++it) {
+        int idx = tid + NT * it;
         int rl = idx / CPR, cc = (idx % CPR) * EPT;
         int m = m0 + rl, n = n0 + cc;
         if (m >= a.M || n >= a.N) continue;
         float v[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; e += 4) {
-            float4 t = *reinterpret_cast<const float4*>(tile + rl * 128 + cc + e);
+            float4 t = *reinterpret_cast<const float4*>(tile + rl * TW + cc + e);
             v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
         }
         bool padrow = false;
@@ -478,6 +479,288 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
     gemm_store_tile<T>(a, tile, m0, n0, tid);
 }
 
+
+// =====================================================================================================
+// Ring-buffered, wave-specialised variant for the large bf16 contractions.
+// 256(M) x 128(N) tile, ONE 512-thread workgroup per CU = two waves per SIMD with different jobs:
+//   waves 0-3  CONSUMERS (2(M) x 2(N), each a 128x64 sub-tile = 4x2 MFMA 32x32x16 blocks, 128 accumulator registers):
+//              ds_read_b128 fragment loads + MFMA only;
+//   waves 4-7  LOADERS: LDS-DMA of the activation / weight tiles into rings of LDS slots, D-1 K-steps ahead.
+// What the measurements said (w_1 k=9 forward, M=43200 N=1024 K=2304; PMC + s_memtime phase timers):
+//   * 128^2 kernels: waves parked 43-63 % of their cycles in vmcnt(0)+barrier at the end of every K-step, ~14
+//     non-MFMA instructions issued per MFMA, MFMA pipe 25-29 % busy;
+//   * issuing one 1-KB LDS-DMA op costs the ISSUING wave 120-260 cycles under load (616 cycles per K-step for 5
+//     ops) wherever it is placed — burst after the barrier or interleaved between MFMA groups — and an in-order
+//     wave cannot issue MFMAs meanwhile.  So the DMA must come from a different wave than the MFMAs: the loader
+//     wave's issue stalls overlap the consumer's matrix work on the same SIMD (guide §5: producer-consumer wave
+//     specialisation as the way past the 128^2 structure's ceiling);
+//   * with the builtin, hipcc drains vmcnt(0) before the first ds_read of every step (it cannot tell which slot a
+//     pending DMA writes), so the DMA is issued from inline asm (guide §5.7) and tracked by hand: each loader waits
+//     with a COUNTED s_waitcnt vmcnt(N) for its own ops of the current step, then the (raw) s_barrier publishes the
+//     slot to the consumers; loads of the next D-2 steps stay in flight across the barrier.
+//   * per-lane source offsets are computed once (32-bit VGPR offset, row clamped into the array); the K/tap advance is
+//     a scalar base (SGPR pair): a DMA op is one s_mov m0 + one global_load_lds, no VALU.
+//   * consumers double-buffer their fragments: the reads of MFMA group g+1 are issued before the MFMAs of group g,
+//     and the first group of the next K-step is fetched right behind that step's barrier while the last group of the
+//     current step is still executing.
+//   conv (taps >= 3): activation halo tile double-buffered, fetched once per Cin-chunk a whole tap-loop early
+//                     (A[kc+1] is issued at tap 0 of chunk kc); weight ring D = 4.      LDS = 2*34 + 1 + 4*16 = 133 KB
+//   taps == 1       : A and B both in rings of D = 3.                                   LDS = 3*32 + 3*16     = 144 KB
+// vmcnt bookkeeping: every loader issues the SAME number of ops per step (A: 9 per conv chunk — loaders that own fewer
+// live 8-row groups pad with dummy loads into a scratch slot — or 8 per step when taps == 1; B: 4 per step), so the
+// number of ops younger than the slot being waited for is a compile-time constant per case.
+// Requires Cin % 64 == 0 and operand footprints < 2 GB (32-bit offsets); the host falls back to the 128^2 kernels
+// otherwise.  Rows outside [0, M) / [0, N) are CLAMPED instead of zero-filled: they only ever feed outputs that are
+// not stored, or taps that the boundary mask zeroes (tiles touching a sequence end always run the MASK variant).
+__device__ __forceinline__ void glds16_sbase(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <bool ONE_TAP> struct RingCfg;
+template <> struct RingCfg<false> { static constexpr int D = 4, A_BYTES = 272 * 128, NA = 2, SCRATCH = 2 * 272 * 128, B_OFF = 2 * 272 * 128 + 1024, NJA = 9; };
+template <> struct RingCfg<true>  { static constexpr int D = 3, A_BYTES = 256 * 128, NA = 3, SCRATCH = 0, B_OFF = 3 * 256 * 128, NJA = 8; };
+static constexpr int RING_B_BYTES = 128 * 128;
+
+// ---- loader waves (lw = 0..3): all DMA of the tile
+template <bool ONE_TAP>
+__device__ __forceinline__ void ring_loader(const ConvGemmArgs& a, unsigned char* smem, int m0, int n0, int lane, int lw) {
+    typedef RingCfg<ONE_TAP> C;
+    constexpr int D = C::D, NJA = C::NJA;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(a.X);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(a.W);
+    const int nkc = a.Cin >> 6;
+    const int taps = ONE_TAP ? 1 : a.taps;
+    const int nsteps = taps * nkc;
+    const int lr = lane >> 3, lc = lane & 7;
+    const int arows = 256 + (taps - 1) * a.dil;
+    const unsigned smem_base = lds_addr(smem);
+
+    unsigned offA[NJA], offB[4], ldsA[NJA];                // per-lane source offsets (bytes); wave-uniform LDS offsets
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) {
+        int wl = lw + 4 * j;
+        const bool live = wl * 8 < arows;                 // wave-uniform
+        int r = wl * 8 + lr;
+        int g = min(max(m0 - a.pad + r, 0), a.M - 1);
+        offA[j] = live ? (unsigned)g * (unsigned)(a.ldx * 2) + (unsigned)((lc ^ ((r >> 1) & 7)) << 4) : 0u;
+        ldsA[j] = live ? (unsigned)(wl * 1024) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = (lw * 4 + j) * 8 + lr;
+        int n = min(n0 + r, a.N - 1);
+        offB[j] = (unsigned)n * (unsigned)(a.ldw * 2) + (unsigned)((lc ^ ((r >> 1) & 7)) << 4);
+    }
+    auto load_A = [&](int kc, int buf) {
+        const unsigned char* base = Xb + (size_t)kc * 128;
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            unsigned d = (ldsA[j] == 0xffffffffu) ? smem_base + C::SCRATCH : smem_base + buf * C::A_BYTES + ldsA[j];
+            glds16_sbase(offA[j], base, __builtin_amdgcn_readfirstlane(d));
+        }
+    };
+    auto load_B = [&](int kc, int tap, int slot) {
+        const unsigned char* base = Wb + ((size_t)tap * a.Cin + (size_t)kc * 64) * 2;
+        const unsigned d0 = smem_base + C::B_OFF + slot * RING_B_BYTES + lw * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_sbase(offB[j], base, d0 + j * 1024);
+    };
+    // issue pointer (ikc, itap, islot) = the step being filled, D-1 ahead of the step being consumed
+    int ikc = 0, itap = 0, islot = 0;
+    auto advance_issue = [&]() {
+        if (++itap == taps) { itap = 0; ++ikc; }
+        if (++islot == D) islot = 0;
+    };
+    if (!ONE_TAP) load_A(0, 0);
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) {
+        if (p < nsteps) {
+            if (ONE_TAP) load_A(ikc, islot);
+            load_B(ikc, itap, islot);
+        }
+        advance_issue();
+    }
+    int step = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        for (int tap = 0; tap < taps; ++tap, ++step) {
+            // my ops of this step have landed: everything but the ops of the younger in-flight steps
+            if (nsteps - 1 - step < D - 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (ONE_TAP) {
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  // (D-2) x (8 A + 4 B)
+            } else {
+                const bool a_young = (tap >= 1 && tap <= D - 2) && (kc + 1 < nkc);  // A[kc+1] was issued <= D-2 steps ago
+                if (a_young) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");     // (D-2) x 4 B + 9 A
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                  // publishes slot(step); consumers are done with slot(step-1)
+            if (!ONE_TAP && tap == 0 && kc + 1 < nkc) load_A(kc + 1, (kc + 1) & 1);
+            if (step + D - 1 < nsteps) {
+                if (ONE_TAP) load_A(ikc, islot);
+                load_B(ikc, itap, islot);
+            }
+            advance_issue();
+        }
+    }
+}
+
+// ---- consumer waves (wave = 0..3 as 2 x 2): fragment reads + MFMA
+template <bool ONE_TAP, bool MASK>
+__device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned char* smem, f32x16 (&acc)[4][2], int m0, int lane,
+                                              int wm, int wn) {
+    typedef RingCfg<ONE_TAP> C;
+    constexpr int D = C::D;
+    const int nkc = a.Cin >> 6;
+    const int taps = ONE_TAP ? 1 : a.taps;
+    const int nsteps = taps * nkc;
+    const int fl = lane & 31, fh = lane >> 5;
+    unsigned boff[4];                                      // B fragment byte offsets inside a slot (nb = 0; nb = 1 is +4096)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = wn * 64 + fl;
+        boff[j] = r * 128 + (((fh * 4 + j) ^ ((r >> 1) & 7)) << 4);
+    }
+    unsigned vmask[4] = {0, 0, 0, 0};
+    if (MASK) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            int m = m0 + wm * 128 + mb * 32 + fl;
+            unsigned msk = 0;
+            if (m < a.M) {
+                int t = m % a.S;
+                for (int j = 0; j < taps; ++j) {
+                    int ts = t + j * a.dil - a.pad;
+                    if (ts >= 0 && ts < a.S) msk |= 1u << j;
+                }
+            }
+            vmask[mb] = msk;
+        }
+    }
+    uint4 af[2][4], bf[2][2];
+    auto read_frags = [&](int set, int kc, int tap, int slot, int j) {
+        const int roff = tap * a.dil;
+        const unsigned a_base = (ONE_TAP ? slot : (kc & 1)) * C::A_BYTES + (wm * 128 + roff) * 128;
+        const unsigned x = ((fl + roff) >> 1) & 7;         // swizzle key of the physical halo row
+        const unsigned aaddr = a_base + fl * 128 + ((((unsigned)(fh * 4 + j)) ^ x) << 4);
+        const unsigned baddr = C::B_OFF + slot * RING_B_BYTES + boff[j];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) bf[set][nb] = *reinterpret_cast<const uint4*>(smem + baddr + nb * 4096);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            af[set][mb] = *reinterpret_cast<const uint4*>(smem + aaddr + mb * 4096);
+            if (MASK && !((vmask[mb] >> tap) & 1u)) af[set][mb] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, af[set][mb]), __builtin_bit_cast(bf16x8, bf[set][nb]), acc[mb][nb], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();                          // slot(0) published
+    read_frags(0, 0, 0, 0, 0);
+    int slot = 0, step = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        for (int tap = 0; tap < taps; ++tap, ++step) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                read_frags((j + 1) & 1, kc, tap, slot, j + 1);
+                mfma_group(j & 1);
+            }
+            // next step's first fragments are fetched behind ITS barrier while this step's last MFMA group runs
+            int nslot = slot + 1; if (nslot == D) nslot = 0;
+            int ntap = tap + 1, nkc_ = kc; if (ntap == taps) { ntap = 0; ++nkc_; }
+            if (step + 1 < nsteps) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the slot about to be refilled are done
+                __builtin_amdgcn_s_barrier();
+                read_frags(0, nkc_, ntap, nslot, 0);
+            }
+            mfma_group(1);
+            slot = nslot;
+        }
+    }
+}
+
+template <bool ONE_TAP>
+__global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int ntm = (a.M + 255) >> 8;
+    const int tile_m = blockIdx.x % ntm, tile_n = blockIdx.x / ntm;
+    const int m0 = tile_m * 256, n0 = tile_n * 128;
+    bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
+
+    if (a.lens) {
+        int mlast = min(m0 + 255, a.M - 1);
+        int b0 = m0 / a.S, b1 = mlast / a.S;
+        if (b0 == b1 && (m0 - b0 * a.S) >= a.lens[b0]) {
+            if (!a.accumulate) {
+                for (int i = tid; i < 256 * 16; i += 512) {              // 16-byte zero stores where the row allows it
+                    int r = i >> 4, c = (i & 15) * 8;
+                    int m = m0 + r, n = n0 + c;
+                    if (m >= a.M || n >= a.N) continue;
+                    bf16_t* yp = Y + (size_t)m * a.ldy + n;
+                    if (a.vec_ok && n + 8 <= a.N) *reinterpret_cast<uint4*>(yp) = make_uint4(0, 0, 0, 0);
+                    else for (int e = 0; e < 8 && n + e < a.N; ++e) yp[e] = 0;
+                }
+            }
+            return;
+        }
+    }
+    f32x16 acc[4][2];
+    if (wave >= 4) {
+        ring_loader<ONE_TAP>(a, smem, m0, n0, lane, wave - 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (ONE_TAP) {
+            ring_consumer<true, false>(a, smem, acc, m0, lane, wm, wn);
+        } else {
+            int t0 = m0 % a.S;
+            int rows = min(256, a.M - m0);
+            const bool need_mask = (t0 < a.pad) || (t0 + rows - 1 + (a.taps - 1) * a.dil - a.pad >= a.S);
+            if (need_mask) ring_consumer<false, true>(a, smem, acc, m0, lane, wm, wn);
+            else ring_consumer<false, false>(a, smem, acc, m0, lane, wm, wn);
+        }
+    }
+    __syncthreads();                                       // every consumer is done reading the operand slots
+
+    // epilogue: the whole 256x128 f32 tile through LDS (128 KB), written by the consumers, stored by all 8 waves
+    float* tile = reinterpret_cast<float*>(smem);
+    if (wave < 4) {
+        const int fl = lane & 31, fh = lane >> 5;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            int cl = wn * 64 + nb * 32 + fl;
+            int n = n0 + cl;
+            float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int rl = wm * 128 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    float v = acc[mb][nb][r] + bv;
+                    if (a.act != FS2_ACT_GATE) v = apply_act(v, a.act, a.slope);
+                    tile[rl * 128 + cl] = v;
+                }
+        }
+    }
+    __syncthreads();
+    gemm_store_tile<bf16_t, 128, 512>(a, tile, m0, n0, tid);
+    gemm_store_tile<bf16_t, 128, 512>(a, tile + 128 * 128, m0 + 128, n0, tid);
+}
+
 extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
                              long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad,
                              int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
@@ -498,7 +781,28 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     // taps == 1 keeps the register-staged kernel (its 3-stage pipeline wins when there is no halo to reuse)
     const bool dma = in_act == FS2_ACT_NONE && taps > 1 && (taps - 1) * dil <= 16 && taps <= 32;
-    if (dma) {
+    // ring-buffered 256x128 tiles once there are enough of them to fill the chip; FS2_GEMM_TILE=128|256 forces a
+    // variant (dev A/B only)
+    static const int force_tile = [] { const char* e = getenv("FS2_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
+    const bool ring_ok = dtype == FS2_BF16 && in_act == FS2_ACT_NONE && (taps == 1 || (taps >= 3 && (taps - 1) * dil <= 16 && taps <= 32)) &&
+                         Cin % 64 == 0 && (double)M * ldx * 2 < 2.0e9 && (double)N * taps * Cin * 2 < 2.0e9;
+    // taps == 1 contractions with a short K (4-12 steps) do not amortise the ring's fill: measured faster on the 128^2 kernel
+    bool big = ring_ok && big_tiles >= 170 && (taps > 1 || Cin >= 1024);
+    if (force_tile == 128) big = false;
+    if (force_tile == 256 && ring_ok) big = true;
+    if (big) {
+        static bool ring_attr_set = false;
+        const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
+        const int dynk = RingCfg<false>::B_OFF + RingCfg<false>::D * RING_B_BYTES;
+        if (!ring_attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn1);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
+            ring_attr_set = true;
+        }
+        if (taps == 1) conv_gemm_ring_kernel<true><<<(unsigned)big_tiles, 512, dyn1, stream>>>(a);
+        else conv_gemm_ring_kernel<false><<<(unsigned)big_tiles, 512, dynk, stream>>>(a);
+    } else if (dma) {
         const int dyn = 2 * 160 * 128 + 2 * 128 * 128;
         static bool attr_set = false;
         if (!attr_set) {

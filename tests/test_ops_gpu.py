@@ -316,3 +316,42 @@ def test_adam_matches_torch(dev):
         hyper = torch.tensor([1e-3, 1 - 0.9 ** step, 1 - 0.98 ** step], device=dev)
         ops.adam_step(pd, gd, m, v, nsq, 1.0, hyper, 0.9, 0.98, 1e-9, 0.0)
     assert torch.allclose(pd.cpu(), pr.detach(), atol=2e-6)
+
+
+@pytest.mark.parametrize("B,S,Cin,Cout,k,dil", [(9, 950, 64, 1024, 9, 1), (8, 1024, 128, 1024, 1, 1), (11, 777, 64, 768, 5, 2),
+                                                (40, 900, 64, 250, 3, 1)])
+def test_conv_gemm_big_tile_bf16(dev, B, S, Cin, Cout, k, dil):
+    """shapes large enough to take the 256x256-tile kernel (>= 128 tiles): ragged lens incl. fully padded tiles,
+    M / N not multiples of 256, residual, accumulate + out_scale, ReLU-gate epilogue."""
+    ops = _ops()
+    torch.manual_seed(3)
+    dtype, tol = torch.bfloat16, 2e-2
+    x = torch.randn(B * S, Cin)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    b = torch.randn(Cout)
+    pad = dil * (k - 1) // 2
+    lens = torch.tensor([max(S - 97 * i, 3) for i in range(B)], dtype=torch.int32)
+    xd = x.to(dev).to(dtype)
+    wf, _ = ops.pack_weight(w.permute(0, 2, 1).contiguous().to(dev), dtype)
+    xr = xd.float().cpu()
+    wr = wf.float().cpu().permute(0, 2, 1).contiguous()
+    base = conv_ref(xr, wr, b, S, dil, pad)
+    padmask = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).reshape(-1)
+    # plain + relu, with and without lens
+    for use_lens in (False, True):
+        y = ops.conv_gemm(xd, wf, b.to(dev), S, taps=k, dil=dil, pad=pad, act=ops.ACT_RELU, lens=lens.to(dev) if use_lens else None)
+        ref = torch.relu(base).clone()
+        if use_lens:
+            ref[padmask] = 0
+        assert rel_err(y.float(), ref) < tol
+    # residual + out_scale + accumulate
+    res = torch.randn(B * S, Cout).to(dtype)
+    y0 = torch.randn(B * S, Cout).to(dtype)
+    out = y0.clone().to(dev)
+    ops.conv_gemm(xd, wf, b.to(dev), S, taps=k, dil=dil, pad=pad, res=res.to(dev), out=out, accumulate=True, out_scale=1.0 / 3)
+    ref = (base + res.double()) / 3 + y0.double()
+    assert rel_err(out.float(), ref) < tol
+    # ReLU gate: y = (R > 0) ? conv : 0
+    g = ops.conv_gemm(xd, wf, None, S, taps=k, dil=dil, pad=pad, act=ops.ACT_GATE, res=res.to(dev))
+    ref = torch.where(res.double() > 0, conv_ref(xr, wr, None, S, dil, pad), torch.zeros(1, dtype=torch.float64))
+    assert rel_err(g.float(), ref) < tol

@@ -19,10 +19,34 @@ def timeit(fn, n=10, warm=3):
     return e0.elapsed_time(e1) / n
 
 
+def vocoder_shapes(dtype=torch.bfloat16):
+    """HiFi-GAN V1 layer shapes at B=8, T=900 mel frames (bench.py --mode synth)."""
+    B, T = 8, 900
+    print("vocoder shapes", dtype)
+    tot = 0.0
+    for (name, C, k, d, up) in [("pre 80->512 k7", 512, 7, 1, 1), ("rb C256 k3", 256, 3, 1, 8), ("rb C256 k7", 256, 7, 3, 8), ("rb C256 k11", 256, 11, 5, 8),
+                                ("rb C128 k3", 128, 3, 1, 64), ("rb C128 k7", 128, 7, 1, 64), ("rb C128 k11", 128, 11, 1, 64),
+                                ("rb C64 k3", 64, 3, 1, 128), ("rb C64 k11", 64, 11, 1, 128), ("rb C32 k3", 32, 3, 1, 256), ("rb C32 k11", 32, 11, 5, 256)]:
+        S = T * up
+        M = B * S
+        Cin = 80 if name.startswith("pre") else C
+        x = torch.randn(M, Cin, device=dev).to(dtype)
+        w = (torch.randn(C, k, Cin, device=dev) / math.sqrt(Cin * k)).to(dtype)
+        b = torch.randn(C, device=dev)
+        y = torch.empty(M, C, device=dev, dtype=dtype)
+        for in_act in ((0,) if name.startswith("pre") else (3, 0)):
+            ms = timeit(lambda: ops.conv_gemm(x, w, b, S, taps=k, dil=d, pad=(k * d - d) // 2, out=y, in_act=in_act, in_slope=0.1))
+            fl = 2.0 * M * Cin * C * k
+            by = M * (Cin + C) * x.element_size()
+            print(f"  {name:16s} in_act={in_act} M={M:8d} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF  {by / ms / 1e6:8.1f} GB/s(min traffic)")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "voc":
+        return vocoder_shapes()
     B, T = 48, 900
     M = B * T
-    for dtype in (torch.float32, torch.bfloat16):
+    for dtype in ((torch.bfloat16,) if len(sys.argv) > 1 and sys.argv[1] == "bf16" else (torch.float32, torch.bfloat16)):
         print("dtype", dtype)
         for (name, Cin, Cout, k) in [("w_1 k9", 256, 1024, 9), ("w_2 k1", 1024, 256, 1), ("qkv", 256, 768, 1), ("fc", 256, 256, 1),
                                      ("postnet k5", 512, 512, 5), ("mel", 256, 80, 1)]:
@@ -34,6 +58,11 @@ def main():
             ms = timeit(lambda: ops.conv_gemm(x, wf, b, T, taps=k, pad=(k - 1) // 2, out=y))
             fl = 2.0 * M * Cin * Cout * k
             print(f"  fwd {name:12s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF")
+            if k > 1 or Cin != Cout:
+                dy_ = torch.randn(M, Cout, device=dev).to(dtype)
+                dx = torch.empty(M, Cin, device=dev, dtype=dtype)
+                ms = timeit(lambda: ops.conv_gemm(dy_, wd, None, T, taps=k, pad=(k - 1) - (k - 1) // 2, out=dx))
+                print(f"  dgrad {name:10s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF")
             dy = torch.randn(M, Cout, device=dev).to(dtype)
             dw = torch.zeros(Cout, k, Cin, device=dev)
             ms = timeit(lambda: ops.conv_wgrad(dy, x, dw, T, taps=k, pad=(k - 1) // 2))
