@@ -860,6 +860,7 @@ struct WgradArgs {
     const void* dY; long lddy;
     const void* X; long ldx;
     float* dW;
+    float* dbias;          // optional: dbias[n] += sum_m dY[m][n], fused into the blocks that own (c-tile 0, tap group 0)
     const int32_t* lens;   // optional: dY rows t >= lens[seq] are known to be zero -> their K-tiles are skipped
     int M, N, Cin, S, taps, dil, pad, rows_per_split;
 };
@@ -1000,6 +1001,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
     const bool ncol_ok = (n0 + sc * 8) < a.N, ccol_ok = (c0 + sc * 8) < a.Cin;
     uint4 ra[4], rb[5];
     bool live_next = true;
+    const bool do_bias = a.dbias != nullptr && tile_c == 0 && tap0 == 0;     // block-uniform
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&](int u) {
         int seq = u / tps, t0 = (u - seq * tps) * 64;
         size_t base = (size_t)seq * a.S;
@@ -1011,6 +1014,17 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ncol_ok && t < tend) v = *reinterpret_cast<const uint4*>(dY + (base + t) * a.lddy + n0 + sc * 8);
             ra[i] = v;
+        }
+        if (do_bias) {                                   // bias gradient rides on the dY tile already in registers
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t* u32 = reinterpret_cast<const uint32_t*>(&ra[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(u32[e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(u32[e] & 0xffff0000u);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
@@ -1091,6 +1105,18 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
         __syncthreads();
     }
     const int fl = lane & 31, fh = lane >> 5;
+    if (do_bias) {                                       // reduce the 16 row-threads of every column group through LDS
+        float* red = reinterpret_cast<float*>(smem);     // [16][128]; the operand tiles are dead (last loop barrier passed)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[sr * 128 + sc * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < a.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+            atomicAdd(a.dbias + n0 + tid, t);
+        }
+    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         int c = c0 + wn * 64 + nb * 32 + fl;
@@ -1128,14 +1154,16 @@ static int launch_wgrad_bf16(WgradArgs a, int S_eff, hipStream_t stream) {
     return 0;
 }
 
-extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, const int32_t* lens, int M, int N,
-                              int Cin, int S, int taps, int dil, int pad, int dtype, hipStream_t stream) {
+extern "C" int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, hipStream_t stream);
+
+extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens,
+                              int M, int N, int Cin, int S, int taps, int dil, int pad, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(dY && X && dW, "conv_wgrad: null pointer");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0, "conv_wgrad: bad shape");
     FS2_CHECK_ARG(N % 4 == 0 && Cin % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0, "conv_wgrad: N/Cin/ld must be multiples of 4");
     if (M == 0) return FS2_OK;
     WgradArgs a;
-    a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps;
+    a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.dbias = dbias; a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps;
     a.dil = dil; a.pad = pad;
     long tiles = (long)fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128) * taps;
     // split rows so that ~1024 workgroups exist, each covering a multiple of 32 rows (>= 256 rows).
@@ -1146,14 +1174,16 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     a.rows_per_split = (int)rps;
     int splits = fs2_cdiv(M, rps);
     dim3 grid((unsigned)tiles, (unsigned)splits);
+    bool bias_fused = false;
     if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) {
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
-        if (fast && taps == 1) launch_wgrad_bf16<1>(a, (lens && M % S == 0) ? S : M, stream);   // no taps, no lens: one "sequence" of M rows
-        else if (fast && 2 * dil <= 8 && M % S == 0) launch_wgrad_bf16<3>(a, S, stream);
+        if (fast && taps == 1) { launch_wgrad_bf16<1>(a, (lens && M % S == 0) ? S : M, stream); bias_fused = true; }   // no taps, no lens: one "sequence" of M rows
+        else if (fast && 2 * dil <= 8 && M % S == 0) { launch_wgrad_bf16<3>(a, S, stream); bias_fused = true; }
         else conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
     } else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("conv_wgrad");
+    if (dbias && !bias_fused) return fs2_colsum(dY, lddy, dbias, M, N, dtype, stream);   // slow paths: separate column-sum pass
     return FS2_OK;
 }
 

@@ -141,8 +141,7 @@ class Engine:
     def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0, lens=None):
         if gw.dim() == 3:
             gw = gw.permute(0, 2, 1)            # tap-major storage of the gradient
-        ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens)
-        ops.colsum(dy, gb)
+        ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
 
     def _fft_fwd(self, W, pre, x, lens, B, S, n_head, p, seed_dev, site, keep):
         ks = self.tc["conv_kernel_size"]

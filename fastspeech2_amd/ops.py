@@ -92,12 +92,12 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     return out
 
 
-def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None):
-    """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x."""
+def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None, dbias=None):
+    """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x;  dbias (Cout,) fp32 += column sums of dy (same pass)."""
     M, N = dy.shape
     Cin = x.shape[1]
-    _lib.call("fs2_conv_wgrad", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(lens), M, N, Cin, S, taps, dil, pad, dt(dy),
-              _stream())
+    _lib.call("fs2_conv_wgrad", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(dbias), _p(lens), M, N, Cin, S, taps, dil,
+              pad, dt(dy), _stream())
 
 
 def colsum(x, out):

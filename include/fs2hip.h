@@ -48,10 +48,11 @@ int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bia
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
  * -> Wf[n][j][c] (forward: dtype cast) and/or Wd[c][j][n] = W[n][k-1-j][c] (data gradient: tap flip + transpose). */
 int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, fs2_stream_t stream);
-/* dW[n][j][c] += sum_m dY[m][n] * X[m + j*dil - pad][c]   (tap-major master layout, f32, atomic accumulate) */
-/* lens (optional): the caller guarantees dY rows t >= lens[b] are zero, so their K-tiles are skipped. */
-int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, const int32_t* lens, int M, int N, int Cin,
-                   int S, int taps, int dil, int pad, int dtype, fs2_stream_t stream);
+/* dW[n][j][c] += sum_m dY[m][n] * X[m + j*dil - pad][c]   (tap-major master layout, f32, atomic accumulate);
+ * dbias (optional): dbias[n] += sum_m dY[m][n], fused into the same pass over dY (the conv/linear bias gradient).
+ * lens (optional): the caller guarantees dY rows t >= lens[b] are zero, so their K-tiles are skipped. */
+int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens, int M,
+                   int N, int Cin, int S, int taps, int dil, int pad, int dtype, fs2_stream_t stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, fs2_stream_t stream);
 

@@ -80,8 +80,10 @@ def test_conv_grads(dev, dtype, tol, B, S, Cin, Cout, k, dil):
     dx = ops.conv_gemm(dyd, wd, None, S, taps=k, dil=dil, pad=(k - 1) * dil - pad)
     assert rel_err(dx.float(), xr.grad) < tol
     dw = torch.zeros(Cout, k, Cin, device=dev)                                      # tap-major gradient
-    ops.conv_wgrad(dyd, xd, dw, S, taps=k, dil=dil, pad=pad)
+    dbf = torch.zeros(Cout, device=dev)                                             # bias gradient fused into the same pass
+    ops.conv_wgrad(dyd, xd, dw, S, taps=k, dil=dil, pad=pad, dbias=dbf)
     assert rel_err(dw.permute(0, 2, 1), wr.grad) < (tol if dtype == torch.float32 else 2e-2)
+    assert rel_err(dbf, dyd.float().cpu().double().sum(0)) < 1e-4
     db = torch.zeros(Cout, device=dev)
     ops.colsum(dyd, db)
     assert rel_err(db, dyd.float().cpu().double().sum(0)) < 1e-4
