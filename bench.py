@@ -197,6 +197,19 @@ def synth_main(args):
         dist.destroy_process_group()
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the roofline kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, collected in separate runs by tools/pmc_traffic.py; counters cannot be read live here)."""
+    path = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"]
+    n = sum(v["launches_per_step"] for name, v in k.items() if kernel_substr in name)
+    b = sum(v["launches_per_step"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for name, v in k.items()
+            if kernel_substr in name)
+    return {"bytes_per_launch": round(b / n), "source": "profiles/r01g_pmc_traffic.json (rocprofv3 --pmc, separate passes)"} if n else None
+
+
 def main():
     args = parse()
     if args.mode == "synth":
@@ -292,9 +305,18 @@ def main():
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s>" % args.dtype, "achieved": round(ach, 1),
-                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            # the big launches (>= 50 GFLOP: k=9 FFN conv and k=5 PostNet conv, forward + data gradient) are the ones the
+            # ring kernel runs; they are the single largest time block of the step
+            big = [(f, e0.elapsed_time(e1)) for (f, e0, e1) in rec if f >= 5e10]
+            big_ach = sum(f for f, _ in big) / (sum(t for _, t in big) * 1e-3) / 1e12 if big else None
+            roofline = {"bound": "mfma", "kernel": "fs2_conv_gemm family (conv_gemm_ring_kernel / conv_gemm_dma_kernel / conv_gemm_kernel, %s)" % args.dtype,
+                        "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": pmc_traffic("conv_gemm"),
                         "launches_per_step": len(rec) // 3, "kernel_ms_per_step": round(ms / 3, 3),
+                        "avg_launch_us": round(ms / len(rec) * 1e3, 1),
+                        "ring_kernel_achieved": round(big_ach, 1) if big_ach else None,
+                        "ring_kernel_frac": round(big_ach / peak, 4) if big_ach else None,
+                        "ring_kernel_ms_per_step": round(sum(t for _, t in big) / 3, 3) if big else None,
                         "step_frac_of_peak": round(value / world * TRAIN_FLOP_PER_FRAME / (peak * 1e12), 4)}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
