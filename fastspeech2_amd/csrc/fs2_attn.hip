@@ -184,9 +184,8 @@ __device__ __forceinline__ bf16x8 frag_t(const unsigned char* lds, int rowbase, 
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ bf16x8 pack8(const float* p) {
-    s16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (short)f32_to_bf16(p[i]);
+    uint4 v;
+    v.x = pack_bf16x2(p[0], p[1]); v.y = pack_bf16x2(p[2], p[3]); v.z = pack_bf16x2(p[4], p[5]); v.w = pack_bf16x2(p[6], p[7]);
     return __builtin_bit_cast(bf16x8, v);
 }
 // load this lane's K-contiguous register fragments of one row (8 steps x 8 bf16), optionally scaled
@@ -199,7 +198,7 @@ __device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* row, int
     }
 }
 
-__global__ void __launch_bounds__(256, 1) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
+__global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
                                                                long ldo, float* __restrict__ lse,
                                                                const int32_t* __restrict__ lens, int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 256];
@@ -392,7 +391,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
     }
 }
 
-__global__ void __launch_bounds__(256, 1) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
+__global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                                   const bf16_t* __restrict__ dctx, long ldo,
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,

@@ -65,7 +65,7 @@ __device__ __forceinline__ uint4 act_chunk_bf16(uint4 v, float slope) {
         float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
         lo = lo > 0.f ? lo : lo * slope;
         hi = hi > 0.f ? hi : hi * slope;
-        u[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+        u[i] = pack_bf16x2(lo, hi);
     }
     return v;
 }
@@ -114,7 +114,7 @@ __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const flo
             }
             uint4 o;
             if constexpr (sizeof(T) == 4) { float* f = reinterpret_cast<float*>(&o); for (int e = 0; e < 4; ++e) f[e] = v[e]; }
-            else { uint32_t* u = reinterpret_cast<uint32_t*>(&o); for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16); }
+            else { uint32_t* u = reinterpret_cast<uint32_t*>(&o); for (int e = 0; e < 4; ++e) u[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]); }
             *reinterpret_cast<uint4*>(yp) = o;
         } else {
             for (int e = 0; e < EPT && n + e < a.N; ++e) {
