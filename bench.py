@@ -80,8 +80,7 @@ def make_step(model, loss_fn, opt, b, exchange):
         loss = fwd_bwd()
         if exchange is not None:
             exchange.finish()
-        opt.step_and_update_lr()
-        opt.zero_grad()
+        opt.step_and_update_lr(zero_grad=True)      # clip + Adam + bf16 weight refresh + gradient clear: one pass
         return loss
 
     return step, fwd_bwd
@@ -249,8 +248,7 @@ def main():
             torch.cuda.synchronize()
             with torch.cuda.graph(graph):
                 static_loss = fwd_bwd()
-                opt.apply_update()
-                model.flat_gradients().zero_()
+                opt.apply_update(zero_grad=True)
             torch.cuda.synchronize()
         except Exception as e:  # capture is an optimisation, never a change of what is computed
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)

@@ -158,24 +158,65 @@ extern "C" int fs2_bucket_embed_add_fwd(const void* x, const float* vals, float 
     FS2_CHECK_LAUNCH("bucket_embed_add_fwd");
     return FS2_OK;
 }
+// demb[bin][:] += sum of the dy rows whose bucket is `bin`.  grid (bin, row-split): the block scans its slice of the
+// bucket indices 256 at a time, compacts the matching row numbers into LDS (ballot + popcount: deterministic order),
+// and its 4 waves add matching rows in parallel from that list (counted loop -> loads pipeline; a lane owns 4 channels
+// of a 256-channel group).  The 4 wave partials meet in LDS; one fp32 atomic per channel and (bin, split) that saw a
+// match.  (The first version issued one atomic per ELEMENT - 1.6 M atomics on a few hot bins, 105 us for 6144 rows.)
 template <typename T>
-__global__ void bucket_embed_bwd_kernel(const int32_t* __restrict__ idx, const T* __restrict__ dy, float* __restrict__ demb,
-                                        int rows, int C) {
-    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    int lane = threadIdx.x & 63;
-    float* g = demb + (size_t)idx[row] * C;
-    const T* d = dy + (size_t)row * C;
-    for (int c = lane * 4; c < C; c += 256) {
-        float4 v = ld4<T>(d + c);
-        atomicAdd(g + c, v.x); atomicAdd(g + c + 1, v.y); atomicAdd(g + c + 2, v.z); atomicAdd(g + c + 3, v.w);
+__global__ void __launch_bounds__(256) bucket_embed_bwd_kernel(const int32_t* __restrict__ idx, const T* __restrict__ dy,
+                                                               float* __restrict__ demb, int rows, int C, int rows_per_split) {
+    __shared__ int s_cnt[4];
+    __shared__ int s_list[256];
+    __shared__ float s_red[4][256 * 4];
+    const int bin = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_split, rend = min(rows, rbeg + rows_per_split);
+    for (int cg = 0; cg < C; cg += 256) {                // channel groups of 256 (one float4 per lane)
+        const int c = cg + lane * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int total = 0;
+        for (int r0 = rbeg; r0 < rend; r0 += 256) {
+            const int r = r0 + threadIdx.x;
+            const bool hit = r < rend && idx[r] == bin;
+            const unsigned long long m = __ballot(hit);
+            __syncthreads();                             // previous chunk's list fully consumed
+            if (lane == 0) s_cnt[w] = __popcll(m);
+            __syncthreads();
+            int base = 0;
+            for (int q = 0; q < w; ++q) base += s_cnt[q];
+            const int n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            if (hit) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+            __syncthreads();
+            total += n;
+            if (c < C) {
+#pragma unroll 4
+                for (int j = w; j < n; j += 4) {
+                    float4 v = ld4<T>(dy + (size_t)s_list[j] * C + c);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+        }
+        if (total == 0) continue;                        // block-uniform
+        __syncthreads();
+        *reinterpret_cast<float4*>(&s_red[w][lane * 4]) = acc;
+        __syncthreads();
+        if (w == 0 && c < C) {
+            float4 t = acc;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) { float4 o = *reinterpret_cast<const float4*>(&s_red[q][lane * 4]); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+            float* g = demb + (size_t)bin * C + c;
+            atomicAdd(g, t.x); atomicAdd(g + 1, t.y); atomicAdd(g + 2, t.z); atomicAdd(g + 3, t.w);
+        }
     }
 }
-extern "C" int fs2_bucket_embed_bwd(const int32_t* idx, const void* dy, float* demb, int rows, int C, int dtype,
+extern "C" int fs2_bucket_embed_bwd(const int32_t* idx, const void* dy, float* demb, int rows, int n_bins, int C, int dtype,
                                     hipStream_t stream) {
     FS2_CHECK_ARG(idx && dy && demb, "bucket_embed_bwd: null pointer");
+    FS2_CHECK_ARG(n_bins > 0 && C > 0 && C % 4 == 0, "bucket_embed_bwd: bad shape n_bins=%d C=%d", n_bins, C);
     if (rows == 0) return FS2_OK;
-    DISPATCH_DTYPE(dtype, bucket_embed_bwd_kernel<T><<<fs2_cdiv(rows, 4), 256, 0, stream>>>(idx, (const T*)dy, demb, rows, C));
+    const int rps = 1024;
+    dim3 grid(n_bins, fs2_cdiv(rows, rps));
+    DISPATCH_DTYPE(dtype, bucket_embed_bwd_kernel<T><<<grid, 256, 0, stream>>>(idx, (const T*)dy, demb, rows, C, rps));
     FS2_CHECK_LAUNCH("bucket_embed_bwd");
     return FS2_OK;
 }

@@ -20,6 +20,7 @@
 // written to the other LDS buffer afterwards (one barrier per K-tile).
 #include "fs2_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -848,6 +849,48 @@ extern "C" int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int
     return FS2_OK;
 }
 
+// Every data-gradient pack of the model in one launch: block = one 64(n) x 64(c) tile of one tap of one weight,
+// transposed through LDS so both the f32 reads (along c) and the packed writes (along n) are contiguous.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_dgrad_multi_kernel(const float* __restrict__ flat, T* __restrict__ wd_base,
+                                                               const int64_t* __restrict__ table, int n_entries) {
+    __shared__ float tile[64][65];
+    int e = 0;
+    while (e + 1 < n_entries && (int)table[(e + 1) * 6 + 5] <= (int)blockIdx.x) ++e;   // <= ~50 entries: linear scan
+    const int64_t* d = table + e * 6;
+    const float* w = flat + d[0];
+    T* wd = wd_base + d[1];
+    const int Cout = (int)d[2], Cin = (int)d[3], k = (int)d[4];
+    int t = (int)blockIdx.x - (int)d[5];
+    const int tn = (Cout + 63) >> 6, tc = (Cin + 63) >> 6;
+    const int in_ = t % tn; t /= tn;
+    const int ic = t % tc; t /= tc;
+    const int j = t;
+    const int n0 = in_ * 64, c0 = ic * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = ly; r < 64; r += 4) {                   // read W[n0+r][j][c0+lx]
+        int n = n0 + r, c = c0 + lx;
+        tile[r][lx] = (n < Cout && c < Cin) ? w[((size_t)n * k + j) * Cin + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ly; r < 64; r += 4) {                   // write Wd[c0+r][k-1-j][n0+lx]
+        int c = c0 + r, n = n0 + lx;
+        if (c < Cin && n < Cout) Elem<T>::st(wd + ((size_t)c * k + (k - 1 - j)) * Cout + n, tile[lx][r]);
+    }
+}
+extern "C" int fs2_pack_dgrad_multi(const float* flat, void* wd_base, const int64_t* table, int n_entries, int total_tiles,
+                                    int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(flat && wd_base && table, "pack_dgrad_multi: null pointer");
+    if (n_entries <= 0 || total_tiles <= 0) return FS2_OK;
+    if (dtype == FS2_F32) pack_dgrad_multi_kernel<float><<<total_tiles, 256, 0, stream>>>(flat, (float*)wd_base, table, n_entries);
+    else if (dtype == FS2_BF16) pack_dgrad_multi_kernel<bf16_t><<<total_tiles, 256, 0, stream>>>(flat, (bf16_t*)wd_base, table, n_entries);
+    else { fs2_set_error("pack_dgrad_multi: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_LAUNCH("pack_dgrad_multi");
+    return FS2_OK;
+}
+
 // ------------------------------------------------------------------ weight gradient (TN contraction over rows)
 // dW[n][j][c] (tap-major master layout, fp32, atomically accumulated; lanes run along c -> coalesced atomics)
 //   = sum_m dY[m][n] * X[m + j*dil - pad][c]
@@ -862,7 +905,7 @@ struct WgradArgs {
     float* dW;
     float* dbias;          // optional: dbias[n] += sum_m dY[m][n], fused into the blocks that own (c-tile 0, tap group 0)
     const int32_t* lens;   // optional: dY rows t >= lens[seq] are known to be zero -> their K-tiles are skipped
-    int M, N, Cin, S, taps, dil, pad, rows_per_split;
+    int M, N, Cin, S, taps, dil, pad, rows_per_split, g3, dbg;
 };
 
 template <typename T>
@@ -968,30 +1011,30 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ uint4 and4(uint4 v, unsigned m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); }
 __device__ __forceinline__ int wg_swz(int row, int c16) { return row * 256 + ((((c16 >> 2) ^ (row & 3))) << 6) + ((c16 & 3) << 4); }
 
-// One workgroup = 128 (n) x 128 (c) outputs for a GROUP of up to TPB adjacent taps, over a range of K-tiles.
-// K-tiles are 64 rows and never straddle a sequence, so the X tile is staged ONCE with a halo of (TPB-1)*dil rows
-// (rows outside the sequence zero-filled) and every tap of the group reads it at a different row offset: the dY and
-// X tiles are fetched once per tap GROUP instead of once per tap.
-template <int TPB>
-__global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
-    constexpr int XROWS = 64 + 8;                       // halo capacity: (TPB-1)*dil <= 8
+// One workgroup = 128 (n) x 128 (c) outputs for a group of EXACTLY NT adjacent taps (compile-time, so the whole K-tile
+// body is straight-line code), over a range of K-tiles.  K-tiles are 64 rows and never straddle a sequence, so the X
+// tile is staged ONCE with a halo of (NT-1)*dil rows (rows outside the sequence zero-filled) and every tap of the
+// group reads it at a different row offset: the dY and X tiles are fetched once per tap GROUP instead of once per tap.
+// What the ISA of the first version showed (r01h): a runtime `tap < ntap` branch around every tap's 4 transposing
+// reads + 4 MFMAs, so each MFMA quartet (128 cycles) waited out a full LDS round trip with nothing in flight ->
+// ~6600 cycles per K-tile against 1536 cycles of MFMA work.  Now: fragments are double-buffered across the four
+// 16-row sub-steps (reads of sub-step s+1 issued before the MFMAs of s), global loads are branch-free (clamped
+// address + select) and issued before the K-tile's MFMAs, stored to the other LDS buffer after them.
+template <int NT>
+__device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned char* smem, int tile_n, int tile_c, int tap0) {
+    constexpr int XROWS = 64 + 8;                       // halo capacity: (NT-1)*dil <= 8
     constexpr int A_BYTES = 64 * 256, X_BYTES = XROWS * 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [buf][dY 64 rows | X 72 rows][256 B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
-    int bx = blockIdx.x;
-    const int tile_n = bx % ntn; bx /= ntn;
-    const int tile_c = bx % ntc; bx /= ntc;
-    const int tap0 = bx * TPB;
-    const int ntap = min(TPB, a.taps - tap0);
     const int n0 = tile_n * 128, c0 = tile_c * 128;
     const int shift0 = tap0 * a.dil - a.pad;
     const int tps = (a.S + 63) >> 6;                    // K-tiles per sequence
     const int nunits = (a.M / a.S) * tps;
-    const int ubeg = blockIdx.y * a.rows_per_split;     // here: units per split
+    const int ubeg = blockIdx.y * a.rows_per_split;     // units per split
     const int uend = min(nunits, ubeg + a.rows_per_split);
     if (ubeg >= uend) return;
     const bf16_t* dY = reinterpret_cast<const bf16_t*>(a.dY);
@@ -999,22 +1042,76 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
 
     const int sr = tid >> 4, sc = tid & 15;
     const bool ncol_ok = (n0 + sc * 8) < a.N, ccol_ok = (c0 + sc * 8) < a.Cin;
-    uint4 ra[4], rb[5];
+    const int ncol = ncol_ok ? n0 + sc * 8 : 0, ccol = ccol_ok ? c0 + sc * 8 : 0;     // clamped: always addressable
+    const bool x5 = wave < 2;                            // halo rows 64..71 are staged by the first 128 threads
+    uint4 ra[4], rb[4], rb4 = make_uint4(0, 0, 0, 0);
     bool live_next = true;
     const bool do_bias = a.dbias != nullptr && tile_c == 0 && tap0 == 0;     // block-uniform
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // INTERIOR K-tiles (all 64 rows valid, whole halo inside the sequence, full column tiles: 13 of 15 at T = 925) take a
+    // fast path: one 32-bit multiply for the thread's first row, scalar strides for the rest, no masks (r01h PMC: 6.9
+    // VALU instructions per MFMA in the first version - address arithmetic and selects - made the loop ISSUE-bound).
+    // EDGE tiles clamp the row index and zero invalid rows when storing.
+    const bool col_full = (n0 + 128 <= a.N) && (c0 + 128 <= a.Cin);
+    const unsigned char* dYb = reinterpret_cast<const unsigned char*>(dY);
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X);
+    const unsigned dy_rs = (unsigned)a.lddy * 2u, x_rs = (unsigned)a.ldx * 2u;      // row strides in bytes
+    const bool small = (double)a.M * (double)dy_rs < 4.0e9 && (double)a.M * (double)x_rs < 4.0e9;   // 32-bit byte offsets
+    unsigned okmask = 0;                                 // edge tiles: bit i: ra[i] valid, bit 4+i: rb[i] valid, bit 8: rb4
+    bool edge_next = false;
     auto load_tile = [&](int u) {
         int seq = u / tps, t0 = (u - seq * tps) * 64;
-        size_t base = (size_t)seq * a.S;
         const int tend = a.lens ? min(a.lens[seq], a.S) : a.S;      // rows >= tend carry zero gradient
         live_next = t0 < tend;
+        if (!live_next) return;                          // block-uniform: a dead K-tile is neither fetched nor multiplied
+        const int row0 = seq * a.S + t0;                 // < M: fits 32 bits
+        edge_next = !col_full || !small || (t0 + 64 > tend) || (t0 + shift0 < 0) || (t0 + shift0 + XROWS > a.S);
+        if (!edge_next) {
+            const unsigned o = (unsigned)(row0 + sr) * dy_rs + (unsigned)ncol * 2u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(dYb + (o + (unsigned)(16 * i) * dy_rs));
+            const unsigned ox = (unsigned)(row0 + shift0 + sr) * x_rs + (unsigned)ccol * 2u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const uint4*>(Xb + (ox + (unsigned)(16 * i) * x_rs));
+            if (x5) rb4 = *reinterpret_cast<const uint4*>(Xb + (ox + 64u * x_rs));
+            return;
+        }
+        size_t base = (size_t)seq * a.S;
+        unsigned ok = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int t = t0 + sr + 16 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ncol_ok && t < tend) v = *reinterpret_cast<const uint4*>(dY + (base + t) * a.lddy + n0 + sc * 8);
-            ra[i] = v;
+            ra[i] = *reinterpret_cast<const uint4*>(dY + (base + min(t, a.S - 1)) * a.lddy + ncol);
+            ok |= (ncol_ok && t < tend) ? (1u << i) : 0u;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int t = t0 + shift0 + sr + 16 * i;
+            rb[i] = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
+            ok |= (ccol_ok && t >= 0 && t < a.S) ? (16u << i) : 0u;
+        }
+        if (x5) {                                        // wave-uniform
+            int t = t0 + shift0 + sr + 64;
+            rb4 = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
+            ok |= (ccol_ok && t >= 0 && t < a.S) ? 256u : 0u;
+        }
+        okmask = ok;
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* As = smem + buf * (A_BYTES + X_BYTES);
+        unsigned char* Bs = As + A_BYTES;
+        if (edge_next) {                                 // block-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = and4(ra[i], 0u - ((okmask >> i) & 1u));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = and4(rb[i], 0u - ((okmask >> (4 + i)) & 1u));
+            rb4 = and4(rb4, 0u - ((okmask >> 8) & 1u));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + wg_swz(sr + 16 * i, sc)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 16 * i, sc)) = rb[i];
+        if (x5) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 64, sc)) = rb4;
         if (do_bias) {                                   // bias gradient rides on the dY tile already in registers
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1026,27 +1123,10 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            int xr = sr + 16 * i;                       // halo-tile row 0..79 (only < XROWS stored)
-            int t = t0 + shift0 + xr;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (live_next && ccol_ok && xr < XROWS && t >= 0 && t < a.S) v = *reinterpret_cast<const uint4*>(X + (base + t) * a.ldx + c0 + sc * 8);
-            rb[i] = v;
-        }
     };
-    auto store_tile = [&](int buf) {
-        unsigned char* As = smem + buf * (A_BYTES + X_BYTES);
-        unsigned char* Bs = As + A_BYTES;
+    f32x16 acc[NT][2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + wg_swz(sr + 16 * i, sc)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (sr + 16 * i < XROWS) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 16 * i, sc)) = rb[i];
-    };
-    f32x16 acc[TPB][2][2];
-#pragma unroll
-    for (int t = 0; t < TPB; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1058,52 +1138,74 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
     const int acol = wm * 64 + 16 * (g & 1) + 4 * (li & 3);
     const int bcol = wn * 64 + 16 * (g & 1) + 4 * (li & 3);
     typedef __attribute__((address_space(3))) s16x4* lds_s4;
-    auto tr_read = [&](const unsigned char* base, int row, int col) -> s16x4 {
-        int off = row * 256 + ((((col >> 5) ^ (row & 3))) << 6) + ((col & 31) << 1);
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + off));
-    };
-    load_tile(ubeg);
-    store_tile(0);
-    __syncthreads();
-    for (int u = ubeg; u < uend; ++u) {
-        const bool live = live_next;
-        if (u + 1 < uend) load_tile(u + 1);
-        const int buf = (u - ubeg) & 1;
-        const unsigned char* As = smem + buf * (A_BYTES + X_BYTES);
-        const unsigned char* Bs = As + A_BYTES;
-        if (live)
+    // per-lane LDS byte offsets of the transposing reads, computed ONCE: sub-step ks adds 16 rows = 4096 B and the
+    // buffer index adds a constant, both of which (row & 3 unchanged) fold into the ds_read immediate offset.
+    auto tr_off = [&](int row, int col) -> unsigned { return (unsigned)(row * 256 + ((((col >> 5) ^ (row & 3))) << 6) + ((col & 31) << 1)); };
+    unsigned offA[2][2], offB[NT][2][2];                 // [blk][lo/hi], [tap][blk][lo/hi]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            s16x8 af[2];
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            offA[blk][hl] = tr_off(rrow + 4 * hl, acol + blk * 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) offB[t][blk][hl] = A_BYTES + tr_off(rrow + 4 * hl + t * a.dil, bcol + blk * 32);
+        }
+    const unsigned smem_u = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto tr_read = [&](unsigned off) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(size_t)(smem_u + off));
+    };
+    s16x8 af[2][2], bf[2][NT][2];                        // [set][..]: fragment double buffer
+    auto read_frags = [&](int set, int bufoff, int ks) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            s16x4 lo = tr_read(offA[blk][0] + bufoff + ks * 4096);
+            s16x4 hi = tr_read(offA[blk][1] + bufoff + ks * 4096);
+            af[set][blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                s16x4 lo = tr_read(As, ks * 16 + rrow, acol + blk * 32);
-                s16x4 hi = tr_read(As, ks * 16 + rrow + 4, acol + blk * 32);
-                af[blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                s16x4 lo = tr_read(offB[t][blk][0] + bufoff + ks * 4096);
+                s16x4 hi = tr_read(offB[t][blk][1] + bufoff + ks * 4096);
+                bf[set][t][blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
+    };
+    auto mma = [&](int set) {
 #pragma unroll
-            for (int t = 0; t < TPB; ++t) {
-                if (t < ntap) {
-                    s16x8 bf[2];
-                    int xo = t * a.dil;
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int blk = 0; blk < 2; ++blk) {
-                        s16x4 lo = tr_read(Bs, ks * 16 + rrow + xo, bcol + blk * 32);
-                        s16x4 hi = tr_read(Bs, ks * 16 + rrow + 4 + xo, bcol + blk * 32);
-                        bf[blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[t][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, af[set][mb]), __builtin_bit_cast(bf16x8, bf[set][t][nb]), acc[t][mb][nb], 0, 0, 0);
+    };
+    load_tile(ubeg);
+    if (live_next) store_tile(0);
+    __syncthreads();
+    // one K-tile out of LDS buffer BUF (compile-time, so every ds_read offset is an immediate)
+    auto ktile = [&](auto bufc, int u) {
+        constexpr int BUF = decltype(bufc)::value;
+        constexpr int bufoff = BUF * (A_BYTES + X_BYTES);
+        const bool live = live_next && !(a.dbg & 2);
+        if (live) read_frags(0, bufoff, 0);
+        if (u + 1 < uend) load_tile(u + 1); else live_next = false;
+        if (live) {
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-                            acc[t][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, af[mb]), __builtin_bit_cast(bf16x8, bf[nb]), acc[t][mb][nb], 0, 0, 0);
-                }
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) read_frags((ks + 1) & 1, bufoff, ks + 1);
+                mma(ks & 1);
             }
         }
-        if (u + 1 < uend) store_tile(buf ^ 1);
+        if (live_next) store_tile(BUF ^ 1);
         __syncthreads();
+    };
+    for (int u = ubeg; u < uend; u += 2) {
+        ktile(std::integral_constant<int, 0>{}, u);
+        if (u + 1 < uend) ktile(std::integral_constant<int, 1>{}, u + 1);
     }
+    if (a.dbg & 1) return;
     const int fl = lane & 31, fh = lane >> 5;
     if (do_bias) {                                       // reduce the 16 row-threads of every column group through LDS
         float* red = reinterpret_cast<float*>(smem);     // [16][128]; the operand tiles are dead (last loop barrier passed)
@@ -1129,29 +1231,45 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
                 if (n >= a.N) continue;
                 float* dst = a.dW + ((size_t)n * a.taps + tap0) * a.Cin + c;
 #pragma unroll
-                for (int t = 0; t < TPB; ++t)
-                    if (t < ntap) atomicAdd(dst + (size_t)t * a.Cin, acc[t][mb][nb][r]);
+                for (int t = 0; t < NT; ++t) atomicAdd(dst + (size_t)t * a.Cin, acc[t][mb][nb][r]);
             }
     }
 }
 
-template <int TPB>
-static int launch_wgrad_bf16(WgradArgs a, int S_eff, hipStream_t stream) {
+// grid.x = (n-tile, c-tile, tap group): the first a.g3 groups take NT taps each, one more group (if REM) the remaining
+// REM taps - k = 9: 3+3+3, k = 5: 3+2, k = 3: 3, k = 1: <1,0> - all in ONE launch (one split-K depth, one set of atomics).
+template <int NT, int REM>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [buf][dY 64 rows | X 72 rows][256 B]
+    const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
+    int bx = blockIdx.x;
+    const int tile_n = bx % ntn; bx /= ntn;
+    const int tile_c = bx % ntc; bx /= ntc;
+    if (REM == 0 || bx < a.g3) wgrad_bf16_body<NT>(a, smem, tile_n, tile_c, bx * NT);
+    else wgrad_bf16_body<(REM ? REM : 1)>(a, smem, tile_n, tile_c, a.g3 * NT);
+}
+
+template <int NT, int REM>
+static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream) {
     a.S = S_eff;
+    a.g3 = g3;
+    static const int dbg = [] { const char* e = getenv("FS2_WGRAD_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     const int dyn = 2 * (64 * 256 + 72 * 256);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
-    int groups = (a.taps + TPB - 1) / TPB;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<NT, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
+    const int groups = g3 + (REM ? 1 : 0);
     long tiles = (long)fs2_cdiv(a.N, 128) * fs2_cdiv(a.Cin, 128) * groups;
     int tps = (a.S + 63) / 64;
     long units = (long)(a.M / a.S) * tps;
-    long want = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU in total
+    static const int wg_target = [] { const char* e = getenv("FS2_WGRAD_WGS"); return e ? atoi(e) : 768; }();
+    long want = (wg_target + tiles - 1) / tiles;        // split-K depth: total workgroups ~ wg_target
     long ups = (units + want - 1) / want;
-    if (ups < 4) ups = 4;
+    static const int min_ups = [] { const char* e = getenv("FS2_WGRAD_MINUPS"); return e ? atoi(e) : 4; }();
+    if (ups < min_ups) ups = min_ups;
     a.rows_per_split = (int)ups;
     dim3 grid((unsigned)tiles, (unsigned)fs2_cdiv(units, ups));
-    conv_wgrad_bf16_kernel<TPB><<<grid, 256, dyn, stream>>>(a);
-    return 0;
+    conv_wgrad_bf16_kernel<NT, REM><<<grid, 256, dyn, stream>>>(a);
 }
 
 extern "C" int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, hipStream_t stream);
@@ -1164,7 +1282,7 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     if (M == 0) return FS2_OK;
     WgradArgs a;
     a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.dbias = dbias; a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps;
-    a.dil = dil; a.pad = pad;
+    a.dil = dil; a.pad = pad; a.g3 = 0; a.dbg = 0;
     long tiles = (long)fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128) * taps;
     // split rows so that ~1024 workgroups exist, each covering a multiple of 32 rows (>= 256 rows).
     long want = (1024 + tiles - 1) / tiles;
@@ -1178,8 +1296,14 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) {
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
-        if (fast && taps == 1) { launch_wgrad_bf16<1>(a, (lens && M % S == 0) ? S : M, stream); bias_fused = true; }   // no taps, no lens: one "sequence" of M rows
-        else if (fast && 2 * dil <= 8 && M % S == 0) { launch_wgrad_bf16<3>(a, S, stream); bias_fused = true; }
+        if (fast && taps == 1) { launch_wgrad_bf16<1, 0>(a, (lens && M % S == 0) ? S : M, 1, stream); bias_fused = true; }   // no taps, no lens: one "sequence" of M rows
+        else if (fast && 2 * dil <= 8 && M % S == 0) {
+            const int g3 = taps / 3, rem = taps - 3 * g3;
+            if (rem == 0) launch_wgrad_bf16<3, 0>(a, S, g3, stream);
+            else if (rem == 2) launch_wgrad_bf16<3, 2>(a, S, g3, stream);
+            else launch_wgrad_bf16<3, 1>(a, S, g3, stream);
+            bias_fused = true;
+        }
         else conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
     } else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("conv_wgrad");

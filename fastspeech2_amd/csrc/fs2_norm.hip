@@ -243,22 +243,26 @@ __global__ void __launch_bounds__(512) ln_bwd_kernel(LnBwdArgs a) {
     }
 }
 
-// sums the per-block partials: block = 32 channels x 8 row-groups; coalesced 128-B reads, LDS tree at the end.
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
-    __shared__ float s[8][32];
-    int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
-    float acc = 0.f;
-    if (c < 2 * C)
-        for (int b = rg; b < nblocks; b += 8) acc += partial[(size_t)b * 2 * C + c];
-    s[rg][threadIdx.x & 31] = acc;
-    __syncthreads();
-    if (rg == 0 && c < 2 * C) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x];
-        if (c < C) dgamma[c] += t; else dbeta[c - C] += t;
+// sums the per-block partials [nblocks][2C]: grid (ceil(2C/256), row-groups); every thread owns one column and walks
+// its row-group with independent (unrolled) coalesced loads, then one atomic per column and row-group (<= 32-way).
+// (r01h: the first version walked all 1024 partial rows with 16 blocks and cost a flat 21 us per LayerNorm.)
+__global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * C) return;
+    const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        acc0 += partial[(size_t)b * 2 * C + c];
+        acc1 += partial[(size_t)(b + 1) * 2 * C + c];
+        acc2 += partial[(size_t)(b + 2) * 2 * C + c];
+        acc3 += partial[(size_t)(b + 3) * 2 * C + c];
     }
+    for (; b < b1; ++b) acc0 += partial[(size_t)b * 2 * C + c];
+    const float t = (acc0 + acc1) + (acc2 + acc3);
+    atomicAdd(c < C ? dgamma + c : dbeta + (c - C), t);
 }
 
 extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
@@ -284,49 +288,144 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     if (dtype == FS2_F32) LN_BWD_NV(float);
     else if (dtype == FS2_BF16) LN_BWD_NV(bf16_t);
     else { fs2_set_error("ln_bwd: dtype"); return FS2_EDTYPE; }
-    ln_bwd_reduce_kernel<<<fs2_cdiv(2 * C, 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
+    ln_bwd_reduce_kernel<<<dim3(fs2_cdiv(2 * C, 256), 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
     FS2_CHECK_LAUNCH("ln_bwd");
     return FS2_OK;
 }
 
 // ================================================================== BatchNorm1d over rows (PostNet)
 // Column statistics over ALL M = B*T rows including padded frames (Appendix A #8).
-// pass 1: sum  -> mean ; pass 2: sum (x-mean)^2 -> biased var.  Partial sums via fp32 atomics.
-template <typename T>
-__global__ void bn_colsum_kernel(const T* __restrict__ x, const float* __restrict__ mean_in, float* __restrict__ out,
-                                 int M, int C, int rows_per_block, float inv_m) {
-    __shared__ float s[4][64];
-    int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    int w = threadIdx.x >> 6;
-    int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
-    float acc = 0.f;
-    if (col < C) {
-        if (mean_in) {
-            float mu = mean_in[col] * inv_m;
-            for (int m = mbeg + w; m < mend; m += 4) { float d = Elem<T>::ld(x + (size_t)m * C + col) - mu; acc += d * d; }
+// Thread mapping of every BN kernel: a thread owns 4 consecutive channels (one 8/16-byte chunk) and walks rows, so a
+// wave reads whole contiguous row segments (the first version mapped one 2-byte element per lane and ran at ~1 TB/s);
+// per-channel constants live in registers.  Chunks per row are padded to a power of two <= 256 so that
+// (chunk, row-lane) is a shift/mask of threadIdx.
+// Statistics in ONE pass: sums of d = x - shift and d^2 with shift = x[0][c] (a sample of the column, so |mean-shift|
+// is of the order of the standard deviation and the variance formula does not cancel), converted afterwards to the
+// (sum, sum of squared deviations) the ABI promises.
+struct BnArgs {
+    const void* x; const void* dout; const void* res; void* out;
+    const float* mean_rstd; const float* gamma; const float* beta;
+    float* sums;                 // stats / bwd sums (2C floats, atomically accumulated)
+    int M, C, cprp, rows_per_block, act;
+    float p; uint64_t seed; const uint64_t* seed_dev;
+};
+
+// MODE 0: statistics   1: apply   2: backward pass 1 (sums)   3: backward pass 2 (dx)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) bn_rows_kernel(BnArgs a) {
+    __shared__ float s_red[2][256 * 4];
+    const T* x = reinterpret_cast<const T*>(a.x);
+    const T* dout = reinterpret_cast<const T*>(a.dout);
+    const T* res = reinterpret_cast<const T*>(a.res);
+    T* out = reinterpret_cast<T*>(a.out);
+    const int chunk = threadIdx.x & (a.cprp - 1), rl = threadIdx.x / a.cprp, nrl = 256 / a.cprp;
+    const int c = chunk * 4;
+    const bool cok = c < a.C;
+    uint64_t seed = a.seed;
+    if (a.seed_dev) seed += *a.seed_dev;
+    const float ik = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, gm[4] = {0, 0, 0, 0}, bt[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+    if (cok) {
+        if (MODE == 0) {
+            float4 s0 = ld4<T>(x + c);
+            mu[0] = s0.x; mu[1] = s0.y; mu[2] = s0.z; mu[3] = s0.w;
         } else {
-            for (int m = mbeg + w; m < mend; m += 4) acc += Elem<T>::ld(x + (size_t)m * C + col);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mu[k] = a.mean_rstd[c + k]; rs[k] = a.mean_rstd[a.C + c + k]; gm[k] = a.gamma[c + k]; bt[k] = a.beta[c + k];
+                if (MODE == 3) { m1[k] = a.sums[c + k] / (float)a.M; m2[k] = a.sums[a.C + c + k] / (float)a.M; }
+            }
         }
     }
-    s[w][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (w == 0 && col < C) atomicAdd(out + col, s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
+    if (cok)
+        for (int r = r0 + rl; r < r1; r += nrl) {
+            const size_t e = (size_t)r * a.C + c;
+            float4 v4 = ld4<T>(x + e);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { float d = v[k] - mu[k]; a1[k] += d; a2[k] += d * d; }
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float o = (v[k] - mu[k]) * rs[k] * gm[k] + bt[k];
+                    if (a.act == FS2_ACT_TANH) o = tanhf(o);
+                    if (a.p > 0.f) o *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
+                    v[k] = o;
+                }
+                if (res) { float4 r4 = ld4<T>(res + e); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
+            } else {
+                float4 g4 = ld4<T>(dout + e);
+                float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float xh = (v[k] - mu[k]) * rs[k];
+                    float gg = g[k];
+                    if (a.p > 0.f) gg *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
+                    if (a.act == FS2_ACT_TANH) { float t = tanhf(xh * gm[k] + bt[k]); gg *= (1.f - t * t); }
+                    if (MODE == 2) { a1[k] += gg; a2[k] += gg * xh; }
+                    else v[k] = gm[k] * rs[k] * (gg - m1[k] - xh * m2[k]);
+                }
+                if (MODE == 3) st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
+            }
+        }
+    if (MODE == 0 || MODE == 2) {                      // reduce over the block's row lanes, then one atomic per channel
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_red[0][threadIdx.x * 4 + k] = a1[k]; s_red[1][threadIdx.x * 4 + k] = a2[k]; }
+        __syncthreads();
+        if (rl == 0 && cok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int j = 0; j < nrl; ++j) { t1 += s_red[0][(j * a.cprp + chunk) * 4 + k]; t2 += s_red[1][(j * a.cprp + chunk) * 4 + k]; }
+                atomicAdd(a.sums + c + k, t1);
+                atomicAdd(a.sums + a.C + c + k, t2);
+            }
+        }
+    }
 }
+
+// shifted sums -> (sum, sum of squared deviations):  sum = S1 + M*shift ;  ssd = S2 - S1^2 / M
+template <typename T>
+__global__ void bn_stats_fix_kernel(const T* __restrict__ x, float* __restrict__ stats, int M, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sh = Elem<T>::ld(x + c), s1 = stats[c], s2 = stats[C + c];
+    stats[c] = s1 + (float)M * sh;
+    stats[C + c] = fmaxf(s2 - s1 * s1 / (float)M, 0.f);
+}
+
+static int bn_geometry(BnArgs& a, int M, int C) {
+    int cpr = C / 4, cprp = 1;
+    while (cprp < cpr) cprp <<= 1;
+    a.cprp = cprp;
+    a.M = M; a.C = C;
+    // ~1000 workgroups, each a whole number of row-lane sweeps
+    int nrl = 256 / cprp;
+    int rpb = fs2_cdiv(M, 1024);
+    rpb = fs2_cdiv(rpb, nrl) * nrl;
+    if (rpb < nrl) rpb = nrl;
+    a.rows_per_block = rpb;
+    return fs2_cdiv(M, rpb);
+}
+#define BN_LAUNCH(MODE, grid) do { \
+    if (dtype == FS2_F32) bn_rows_kernel<float, MODE><<<grid, 256, 0, stream>>>(a); \
+    else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE><<<grid, 256, 0, stream>>>(a); \
+    else { fs2_set_error("bn: dtype"); return FS2_EDTYPE; } } while (0)
 
 // stats[0..C) = sum, stats[C..2C) = sum of squared deviations  (caller zeroes stats first)
 extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && stats, "bn_stats: null pointer");
-    FS2_CHECK_ARG(M > 0 && C > 0, "bn_stats: bad shape");
-    int rpb = 128;
-    dim3 grid(fs2_cdiv(C, 64), fs2_cdiv(M, rpb));
-    float inv_m = 1.0f / (float)M;
-    if (dtype == FS2_F32) {
-        bn_colsum_kernel<float><<<grid, 256, 0, stream>>>((const float*)x, nullptr, stats, M, C, rpb, inv_m);
-        bn_colsum_kernel<float><<<grid, 256, 0, stream>>>((const float*)x, stats, stats + C, M, C, rpb, inv_m);
-    } else if (dtype == FS2_BF16) {
-        bn_colsum_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)x, nullptr, stats, M, C, rpb, inv_m);
-        bn_colsum_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)x, stats, stats + C, M, C, rpb, inv_m);
-    } else { fs2_set_error("bn_stats: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_stats: bad shape M=%d C=%d", M, C);
+    BnArgs a = {};
+    a.x = x; a.sums = stats;
+    int grid = bn_geometry(a, M, C);
+    BN_LAUNCH(0, grid);
+    if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
+    else bn_stats_fix_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats, M, C);
     FS2_CHECK_LAUNCH("bn_stats");
     return FS2_OK;
 }
@@ -358,96 +457,37 @@ extern "C" int fs2_bn_finalize(const float* stats, float* running_mean, float* r
     return FS2_OK;
 }
 
-// out = drop(act((x-mean)*rstd*gamma+beta))
-template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ out, size_t total4,
-                                int C, int act, float p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
-    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    if (seed_dev) seed += *seed_dev;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        size_t e = i * 4;
-        int c = (int)(e % C);
-        float4 v = ld4<T>(x + e);
-        float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float o = (vv[k] - mean_rstd[c + k]) * mean_rstd[C + c + k] * gamma[c + k] + beta[c + k];
-            if (act == FS2_ACT_TANH) o = tanhf(o);
-            if (p > 0.f) o *= fs2_drop_scale(seed, (uint32_t)(e + k), p, ik);
-            vv[k] = o;
-        }
-        if (res) { float4 r = ld4<T>(res + e); vv[0] += r.x; vv[1] += r.y; vv[2] += r.z; vv[3] += r.w; }
-        st4<T>(out + e, make_float4(vv[0], vv[1], vv[2], vv[3]));
-    }
-}
+// out = drop(act((x-mean)*rstd*gamma+beta)) (+ res)
 extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, const void* res,
                             void* out, int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
                             hipStream_t stream) {
     FS2_CHECK_ARG(x && mean_rstd && gamma && beta && out, "bn_apply: null pointer");
-    FS2_CHECK_ARG(C % 4 == 0, "bn_apply: C%%4");
-    size_t total4 = (size_t)M * C / 4;
-    if (total4 == 0) return FS2_OK;
-    int grid = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-    if (dtype == FS2_F32) bn_apply_kernel<float><<<grid, 256, 0, stream>>>((const float*)x, mean_rstd, gamma, beta, (const float*)res, (float*)out, total4, C, act, p, seed, seed_dev);
-    else if (dtype == FS2_BF16) bn_apply_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)res, (bf16_t*)out, total4, C, act, p, seed, seed_dev);
-    else { fs2_set_error("bn_apply: dtype"); return FS2_EDTYPE; }
+    FS2_CHECK_ARG(C % 4 == 0 && C <= 1024, "bn_apply: C=%d must be a multiple of 4, <= 1024", C);
+    if ((size_t)M * C == 0) return FS2_OK;
+    BnArgs a = {};
+    a.x = x; a.res = res; a.out = out; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.act = act; a.p = p;
+    a.seed = seed; a.seed_dev = seed_dev;
+    int grid = bn_geometry(a, M, C);
+    BN_LAUNCH(1, grid);
     FS2_CHECK_LAUNCH("bn_apply");
     return FS2_OK;
 }
 
 // Backward, pass 1: g = dout * dropmask * act'(.)  ;  sums[c] += g, sums[C+c] += g*xhat  (also = dbeta, dgamma)
 //           pass 2: dx = gamma*rstd*(g - sums[c]/M - xhat*sums[C+c]/M)
-template <typename T, int PASS>
-__global__ void bn_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ mean_rstd,
-                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sums,
-                              T* __restrict__ dx, int M, int C, int rows_per_block, int act, float p, uint64_t seed,
-                              const uint64_t* __restrict__ seed_dev) {
-    __shared__ float s[2][4][64];
-    if (seed_dev) seed += *seed_dev;
-    int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    int w = threadIdx.x >> 6;
-    int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
-    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    float a1 = 0.f, a2 = 0.f;
-    if (col < C) {
-        float mu = mean_rstd[col], rs = mean_rstd[C + col], gm = gamma[col], bt = beta[col];
-        float m1 = 0.f, m2 = 0.f;
-        if (PASS == 2) { m1 = sums[col] / (float)M; m2 = sums[C + col] / (float)M; }
-        for (int m = mbeg + w; m < mend; m += 4) {
-            size_t e = (size_t)m * C + col;
-            float xh = (Elem<T>::ld(x + e) - mu) * rs;
-            float g = Elem<T>::ld(dout + e);
-            if (p > 0.f) g *= fs2_drop_scale(seed, (uint32_t)e, p, ik);
-            if (act == FS2_ACT_TANH) { float t = tanhf(xh * gm + bt); g *= (1.f - t * t); }
-            if (PASS == 1) { a1 += g; a2 += g * xh; }
-            else Elem<T>::st(dx + e, gm * rs * (g - m1 - xh * m2));
-        }
-    }
-    if (PASS == 1) {
-        s[0][w][threadIdx.x & 63] = a1; s[1][w][threadIdx.x & 63] = a2;
-        __syncthreads();
-        if (w == 0 && col < C) {
-            atomicAdd(sums + col, s[0][0][threadIdx.x] + s[0][1][threadIdx.x] + s[0][2][threadIdx.x] + s[0][3][threadIdx.x]);
-            atomicAdd(sums + C + col, s[1][0][threadIdx.x] + s[1][1][threadIdx.x] + s[1][2][threadIdx.x] + s[1][3][threadIdx.x]);
-        }
-    }
-}
 // sums (2C floats, zeroed by the caller) receives dbeta (first C) and dgamma (last C).
 extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
                           float* sums, void* dx, int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev,
                           int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && dout && mean_rstd && gamma && beta && sums && dx, "bn_bwd: null pointer");
-    int rpb = 128;
-    dim3 grid(fs2_cdiv(C, 64), fs2_cdiv(M, rpb));
+    FS2_CHECK_ARG(C % 4 == 0 && C <= 1024, "bn_bwd: C=%d must be a multiple of 4, <= 1024", C);
     if (M == 0) return FS2_OK;
-    if (dtype == FS2_F32) {
-        bn_bwd_kernel<float, 1><<<grid, 256, 0, stream>>>((const float*)x, (const float*)dout, mean_rstd, gamma, beta, sums, (float*)dx, M, C, rpb, act, p, seed, seed_dev);
-        bn_bwd_kernel<float, 2><<<grid, 256, 0, stream>>>((const float*)x, (const float*)dout, mean_rstd, gamma, beta, sums, (float*)dx, M, C, rpb, act, p, seed, seed_dev);
-    } else if (dtype == FS2_BF16) {
-        bn_bwd_kernel<bf16_t, 1><<<grid, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)dout, mean_rstd, gamma, beta, sums, (bf16_t*)dx, M, C, rpb, act, p, seed, seed_dev);
-        bn_bwd_kernel<bf16_t, 2><<<grid, 256, 0, stream>>>((const bf16_t*)x, (const bf16_t*)dout, mean_rstd, gamma, beta, sums, (bf16_t*)dx, M, C, rpb, act, p, seed, seed_dev);
-    } else { fs2_set_error("bn_bwd: dtype"); return FS2_EDTYPE; }
+    BnArgs a = {};
+    a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
+    a.p = p; a.seed = seed; a.seed_dev = seed_dev;
+    int grid = bn_geometry(a, M, C);
+    BN_LAUNCH(2, grid);
+    BN_LAUNCH(3, grid);
     FS2_CHECK_LAUNCH("bn_bwd");
     return FS2_OK;
 }

@@ -32,6 +32,8 @@ class Engine:
         self.cdt = model.compute_dtype
         self.weights_dirty = True
         self._packed = {}
+        self._flat_lp = None
+        self.lp_synced = False
         self._pe_cache = {}
         self.seed_counter = torch.zeros(1, device=device, dtype=torch.int64)
         self.base_seed = 0
@@ -79,25 +81,64 @@ class Engine:
             out.append((pre, self.P[pre + ".weight"], self.P[pre + ".bias"]))
         return out
 
-    def weights(self, need_dgrad):
-        """Packed compute-dtype copies of every weight: Wf[n][tap][c] (+ Wd[c][tap][n] for data gradients)."""
-        if not self.weights_dirty and self._packed and (self._packed_has_dgrad or not need_dgrad):
-            return self._packed
-        packed = {}
+    def _build_layout(self):
+        """One-time description of every contraction's weight inside the flat parameter buffer: the forward pack of a
+        layer is a VIEW (master weights are stored in the GEMM's own [n][tap][c] order; for bf16 compute the view is into
+        the bf16 shadow copy of the flat buffer that the Adam kernel maintains), the data-gradient packs live in one
+        buffer filled by a single fs2_pack_dgrad_multi launch."""
+        m = self.m
+        lowp = self.cdt != torch.float32
+        flat = m._flat
+        self._flat_lp = torch.empty(flat.numel(), device=flat.device, dtype=self.cdt) if lowp else None
+        self.lp_synced = False
+        src = self._flat_lp if lowp else flat
+        entries, rows, wd_off, tile0 = [], [], 0, 0
+        base = flat.data_ptr()
         for key, w, b in self._conv_list():
             if w.dim() == 3:
-                w = w.permute(0, 2, 1)          # the contiguous tap-major storage [Cout][k][Cin]
-            prev = self._packed.get(key)
-            wf = prev[0] if prev is not None else None
-            wd = prev[1] if (prev is not None and prev[1] is not None) else None
-            if self.cdt == torch.float32:
-                wf = None                        # f32 compute reads the master weights in place
-            wf, wd = ops.pack_weight(w, self.cdt, want_fwd=True, want_dgrad=need_dgrad, wf=wf, wd=wd if need_dgrad else None)
-            packed[key] = (wf, wd if need_dgrad else (prev[1] if prev is not None else None), b, w.shape)
+                w = w.permute(0, 2, 1)                  # the contiguous tap-major storage [Cout][k][Cin]
+                cout, k, cin = w.shape
+            else:
+                cout, cin = w.shape
+                k = 1
+            assert w.is_contiguous()
+            off = (w.data_ptr() - base) // 4
+            n = cout * k * cin
+            entries.append((key, off, wd_off, cout, cin, k, b))
+            rows.append([off, wd_off, cout, cin, k, tile0])
+            wd_off += (n + 7) // 8 * 8
+            tile0 += ((cout + 63) // 64) * ((cin + 63) // 64) * k
+        self._wd_all = torch.empty(wd_off, device=flat.device, dtype=self.cdt)
+        self._pack_table = torch.tensor(rows, dtype=torch.int64, device=flat.device)
+        self._pack_tiles = tile0
+        packed = {}
+        for key, off, wdo, cout, cin, k, b in entries:
+            n = cout * k * cin
+            wf = src[off:off + n].view(cout, k, cin)
+            wd = self._wd_all[wdo:wdo + n].view(cin, k, cout)
+            packed[key] = (wf, wd, b, (cout, k, cin))
         self._packed = packed
-        self._packed_has_dgrad = need_dgrad
-        self.weights_dirty = False
-        return packed
+        self._packed_has_dgrad = False
+
+    def lowp_buffer(self):
+        """bf16 shadow of the flat parameter buffer (None for fp32 compute); the Adam kernel writes it in its own pass."""
+        if not self._packed:
+            self._build_layout()
+        return self._flat_lp
+
+    def weights(self, need_dgrad):
+        """Compute-dtype weights of every contraction: Wf[n][tap][c] views (+ Wd[c][tap][n] packs for data gradients)."""
+        if not self._packed:
+            self._build_layout()
+        if self.weights_dirty or (need_dgrad and not self._packed_has_dgrad):
+            if self._flat_lp is not None and not self.lp_synced:
+                ops.cast(self.m._flat, self.cdt, out=self._flat_lp)
+                self.lp_synced = True
+            if need_dgrad:
+                ops.pack_dgrad_multi(self.m._flat, self._wd_all, self._pack_table, self._pack_tiles)
+            self._packed_has_dgrad = need_dgrad
+            self.weights_dirty = False
+        return self._packed
 
     def _grads(self):
         if self.G is None:

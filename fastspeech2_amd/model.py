@@ -243,9 +243,12 @@ class FastSpeech2(nn.Module):
         assert sorted(order) == sorted(trainable), "flat layout does not cover the trainable parameters"
         return [(n, named[n]) for n in order]
 
-    def _invalidate(self):
+    def _invalidate(self, lowp_synced=False):
+        """parameters changed: the engine must refresh its packed weights (lowp_synced: the bf16 shadow copy of the
+        flat buffer is already up to date - the Adam kernel wrote it)."""
         if self._engine is not None:
             self._engine.weights_dirty = True
+            self._engine.lp_synced = bool(lowp_synced)
 
     def _ensure_flat(self, device):
         """(Re)build the flat fp32 parameter / gradient buffers on `device` and alias every Parameter to it."""
@@ -257,7 +260,7 @@ class FastSpeech2(nn.Module):
         offsets, total = {}, 0
         for n, p in pairs:
             offsets[n] = total
-            total += (p.numel() + 3) // 4 * 4            # keep every view 16-byte aligned
+            total += (p.numel() + 7) // 8 * 8            # every view 16-byte aligned in fp32 AND in the bf16 shadow copy
         flat = torch.zeros(total, device=device, dtype=torch.float32)
         grad = torch.zeros(total, device=device, dtype=torch.float32)
         for n, p in pairs:
@@ -402,25 +405,28 @@ class ScheduledOptim:
                 self._load_now(self._pending_state)
                 self._pending_state = None
 
-    def step_and_update_lr(self):
+    def step_and_update_lr(self, zero_grad=False):
+        """optimizer.py:22-24.  zero_grad=True also clears the gradients inside the Adam pass (then skip zero_grad())."""
         self._ensure()
         self.current_step += 1
         self._adam_step += 1
         lr = self.init_lr * self._get_lr_scale()
         b1, b2 = self.betas
         self._hyper.copy_(torch.tensor([lr, 1 - b1 ** self._adam_step, 1 - b2 ** self._adam_step, 0.0]), non_blocking=True)
-        self.apply_update()
+        self.apply_update(zero_grad=zero_grad)
         self.last_lr = lr
 
-    def apply_update(self):
-        """The capturable part: ||g||^2, then clip+Adam over the flat buffers (reads lr / bias corrections from device)."""
+    def apply_update(self, zero_grad=False):
+        """The capturable part: ||g||^2, then clip+Adam over the flat buffers (reads lr / bias corrections from device).
+        The same pass refreshes the bf16 shadow parameters the forward GEMMs read and (optionally) clears the gradients."""
         b1, b2 = self.betas
         g = self.model.flat_gradients()
         self._nsq.zero_()
         ops.sumsq(g, self._nsq)
+        lowp = self.model._engine.lowp_buffer() if self.model._engine is not None else None
         ops.adam_step(self.model.flat_parameters(), g, self._m, self._v, self._nsq, self.grad_clip_thresh, self._hyper,
-                      b1, b2, self.eps, self.weight_decay)
-        self.model._invalidate()
+                      b1, b2, self.eps, self.weight_decay, p_lowp=lowp, zero_grad=zero_grad)
+        self.model._invalidate(lowp_synced=lowp is not None)
 
     def zero_grad(self):
         g = self.model.flat_gradients()

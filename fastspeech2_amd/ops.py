@@ -201,7 +201,7 @@ def bucket_embed_add_fwd(x, vals, scale, bins, emb):
 
 def bucket_embed_bwd(idx, dy, demb):
     rows, C = dy.shape
-    _lib.call("fs2_bucket_embed_bwd", _p(idx), _p(dy), _p(demb), rows, C, dt(dy), _stream())
+    _lib.call("fs2_bucket_embed_bwd", _p(idx), _p(dy), _p(demb), rows, demb.shape[0], C, dt(dy), _stream())
 
 
 def lr_index(durations, T):
@@ -255,8 +255,9 @@ def mask_rows(x, lens, B, S):
     return x
 
 
-def cast(x, dtype):
-    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+def cast(x, dtype, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
     _lib.call("fs2_cast", _p(x), dt(x), _p(out), dt(dtype), x.numel(), _stream())
     return out
 
@@ -266,9 +267,14 @@ def sumsq(x, out):
     _lib.call("fs2_sumsq", _p(x), x.numel(), _p(out), _stream())
 
 
-def adam_step(p, g, m, v, gnorm_sq, max_norm, hyper, b1, b2, eps, wd):
+def adam_step(p, g, m, v, gnorm_sq, max_norm, hyper, b1, b2, eps, wd, p_lowp=None, zero_grad=False):
+    """clip + Adam over the flat buffers; optionally writes the bf16 shadow copy of p and clears g in the same pass."""
     _lib.call("fs2_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(gnorm_sq), float(max_norm), _p(hyper), b1, b2,
-              eps, wd, _stream())
+              eps, wd, _p(p_lowp), BF16 if p_lowp is not None else 0, int(zero_grad), _stream())
+
+
+def pack_dgrad_multi(flat, wd_all, table, total_tiles):
+    _lib.call("fs2_pack_dgrad_multi", _p(flat), _p(wd_all), _p(table), table.shape[0], total_tiles, dt(wd_all), _stream())
 
 
 def add(a, b, out=None):

@@ -48,6 +48,11 @@ int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bia
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
  * -> Wf[n][j][c] (forward: dtype cast) and/or Wd[c][j][n] = W[n][k-1-j][c] (data gradient: tap flip + transpose). */
 int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, fs2_stream_t stream);
+/* All data-gradient packs of a model in ONE launch.  table (device, int64 [n_entries][6]) = {src element offset into
+ * flat, dst element offset into wd_base, Cout, Cin, k, first 64x64 tile index}; total_tiles = sum over entries of
+ * ceil(Cout/64)*ceil(Cin/64)*k.  Each entry is packed as fs2_pack_weight's Wd (tap flip + transpose, LDS-tiled). */
+int fs2_pack_dgrad_multi(const float* flat, void* wd_base, const int64_t* table, int n_entries, int total_tiles, int dtype,
+                         fs2_stream_t stream);
 /* dW[n][j][c] += sum_m dY[m][n] * X[m + j*dil - pad][c]   (tap-major master layout, f32, atomic accumulate);
  * dbias (optional): dbias[n] += sum_m dY[m][n], fused into the same pass over dY (the conv/linear bias gradient).
  * lens (optional): the caller guarantees dY rows t >= lens[b] are zero, so their K-tiles are skipped. */
@@ -104,7 +109,8 @@ int fs2_rowvec_bwd(const void* dy, float* dtable, const int64_t* idx, int B, int
 int fs2_bucket_embed_add_fwd(const void* x, const float* vals, float scale, const float* bins, int nbins,
                              const float* emb, void* out, int32_t* idx_out, int rows, int C, int dtype,
                              fs2_stream_t stream);
-int fs2_bucket_embed_bwd(const int32_t* idx, const void* dy, float* demb, int rows, int C, int dtype,
+/* demb[n_bins][C] (fp32) += rows of dy grouped by bucket index (gather-reduce per bin, one atomic per channel and row split) */
+int fs2_bucket_embed_bwd(const int32_t* idx, const void* dy, float* demb, int rows, int n_bins, int C, int dtype,
                          fs2_stream_t stream);
 /* model/modules.py:167-194 LengthRegulator (+ utils/tools.py:299-317 pad): integer index map, bit-exact.
  * cum [B][L+1] int32 exclusive prefix sums of max((int)d,0); idx [B][T] frame->phoneme (-1 = padding);
@@ -157,9 +163,12 @@ int fs2_stft_mel_epilogue(const float* ft, long ldft, const float* mel_basis, co
 
 /* ---- optimiser: train.py:93 clip_grad_norm_ + model/optimizer.py:10-51 Adam ------------------------- */
 int fs2_sumsq(const float* x, size_t n, float* out /*+=*/, fs2_stream_t stream);
-/* hyper (device) = {lr, 1-beta1^t, 1-beta2^t}; clip = min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) */
-int fs2_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* gnorm_sq, float max_norm,
-                  const float* hyper, float b1, float b2, float eps, float wd, fs2_stream_t stream);
+/* hyper (device) = {lr, 1-beta1^t, 1-beta2^t}; clip = min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)).
+ * p_lowp (optional, bf16): compute-dtype copy of the updated parameters written in the same pass;
+ * zero_grad: clear g as it is consumed (optimizer.zero_grad(), model/optimizer.py:30-31).  n % 4 == 0. */
+int fs2_adam_step(float* p, float* g, float* m, float* v, size_t n, const float* gnorm_sq, float max_norm,
+                  const float* hyper, float b1, float b2, float eps, float wd, void* p_lowp, int lowp_dtype, int zero_grad,
+                  fs2_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -357,3 +357,84 @@ def test_conv_gemm_big_tile_bf16(dev, B, S, Cin, Cout, k, dil):
     g = ops.conv_gemm(xd, wf, None, S, taps=k, dil=dil, pad=pad, act=ops.ACT_GATE, res=res.to(dev))
     ref = torch.where(res.double() > 0, conv_ref(xr, wr, None, S, dil, pad), torch.zeros(1, dtype=torch.float64))
     assert rel_err(g.float(), ref) < tol
+
+
+@pytest.mark.parametrize("rows,C,hot", [(60, 256, False), (6144, 256, True), (3000, 512, True)])
+def test_bucket_embed_bwd(dev, rows, C, hot):
+    """gather-reduce per bin (with a hot bin holding every padded position, as zero pitch targets do) vs index_add_."""
+    ops = _ops()
+    torch.manual_seed(21)
+    nb = 256
+    idx = torch.randint(0, nb, (rows,), dtype=torch.int32)
+    if hot:
+        idx[torch.rand(rows) < 0.3] = 52
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 1e-4)):
+        dy = torch.randn(rows, C).to(dtype)
+        demb = torch.ones(nb, C, device=dev)                     # accumulates INTO the gradient buffer
+        ops.bucket_embed_bwd(idx.to(dev), dy.to(dev), demb)
+        ref = torch.ones(nb, C, dtype=torch.double).index_add_(0, idx.long(), dy.double())
+        assert rel_err(demb, ref) < tol
+
+
+def test_pack_dgrad_multi_matches_single(dev):
+    ops = _ops()
+    torch.manual_seed(22)
+    shapes = [(1024, 256, 9), (256, 1024, 1), (80, 256, 1), (512, 80, 5), (768, 256, 1), (100, 72, 3)]
+    for dtype in (torch.float32, torch.bfloat16):
+        chunks, rows, off, wdo, tile0 = [], [], 0, 0, 0
+        for (co, ci, k) in shapes:
+            w = torch.randn(co, k, ci)
+            chunks.append(w.reshape(-1))
+            rows.append([off, wdo, co, ci, k, tile0])
+            n = co * ci * k
+            off += n; wdo += (n + 7) // 8 * 8
+            tile0 += ((co + 63) // 64) * ((ci + 63) // 64) * k
+        flat = torch.cat(chunks).to(dev)
+        wd_all = torch.zeros(wdo, device=dev, dtype=dtype)
+        ops.pack_dgrad_multi(flat, wd_all, torch.tensor(rows, dtype=torch.int64, device=dev), tile0)
+        for (co, ci, k), r in zip(shapes, rows):
+            w = flat[r[0]:r[0] + co * ci * k].view(co, k, ci)
+            _, wd = ops.pack_weight(w, dtype)
+            got = wd_all[r[1]:r[1] + co * ci * k].view(ci, k, co)
+            assert torch.equal(got, wd), (co, ci, k, dtype)
+
+
+def test_adam_fused_shadow_and_zero_grad(dev):
+    ops = _ops()
+    torch.manual_seed(23)
+    n = 4096 * 8
+    p = torch.randn(n, device=dev); g = torch.randn(n, device=dev)
+    p2, g2 = p.clone(), g.clone()
+    m, v, m2, v2 = (torch.zeros(n, device=dev) for _ in range(4))
+    nsq = torch.zeros(1, device=dev)
+    ops.sumsq(g, nsq)
+    hyper = torch.tensor([1e-3, 0.1, 0.02, 0.0], device=dev)
+    ops.adam_step(p, g, m, v, nsq, 1.0, hyper, 0.9, 0.98, 1e-9, 0.0)
+    lp = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    ops.adam_step(p2, g2, m2, v2, nsq, 1.0, hyper, 0.9, 0.98, 1e-9, 0.0, p_lowp=lp, zero_grad=True)
+    assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+    assert torch.equal(lp, p2.to(torch.bfloat16))
+    assert torch.count_nonzero(g2).item() == 0 and torch.count_nonzero(g).item() > 0
+
+
+@pytest.mark.parametrize("M,C", [(1000, 80), (333, 512), (64, 4)])
+def test_batchnorm_shapes(dev, M, C):
+    """row-chunk mapping at channel counts that are not a power of two / tiny, large column means (shifted sums)."""
+    ops = _ops()
+    torch.manual_seed(24)
+    x = torch.randn(M, C) * 0.5 + 30.0                          # |mean| >> std: a naive E[x^2]-E[x]^2 would cancel
+    gamma = torch.rand(C) + 0.5; beta = torch.randn(C) * 0.1
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    rm = torch.zeros(C, dtype=torch.double); rv = torch.ones(C, dtype=torch.double)
+    res = torch.randn(M, C)
+    ref = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5) + res.double()
+    rmd = torch.zeros(C, device=dev); rvd = torch.ones(C, device=dev)
+    out, mean_rstd = ops.bn_train_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmd, rvd, ops.ACT_NONE, 0.0, 0, res=res.to(dev))
+    assert rel_err(out, ref.detach()) < 2e-4
+    assert rel_err(rmd, rm) < 1e-4 and rel_err(rvd, rv) < 2e-3
+    dout = torch.randn(M, C)
+    ref.backward(dout.double())
+    dx, dgam, dbet = ops.bn_bwd(x.to(dev), dout.to(dev), mean_rstd, gamma.to(dev), beta.to(dev), ops.ACT_NONE, 0.0, 0)
+    assert rel_err(dx, xr.grad) < 2e-3
+    assert rel_err(dgam, gr.grad) < 2e-3 and rel_err(dbet, br.grad) < 1e-4

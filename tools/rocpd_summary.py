@@ -18,3 +18,16 @@ print("|---|---|---|---|---|---|---|")
 for n, cnt, tot, mn, mx in rows[:40]:
     short = re.sub(r"\(.*", "", n)[:90]
     print(f"| {short} | {cnt} | {tot/1e6:.3f} | {tot/cnt/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} | {100*tot/total:.1f} |")
+
+# ---- per-shape breakdown: the same kernel grouped by launch geometry (grid), so each layer shape shows up separately
+gcols = [c_ for c_ in cols if "grid" in c_.lower()]
+if gcols and len(sys.argv) > 3 and sys.argv[3] == "shapes":
+    gsel = ", ".join(gcols)
+    rows = c.execute(f"select {name_col}, {gsel}, count(*), sum(end-start), min(end-start) from kernels group by {name_col}, {gsel} order by sum(end-start) desc").fetchall()
+    print("\n## per launch geometry (top 60)\n")
+    print("| kernel | grid | calls/step | avg us | min us | ms/step |")
+    print("|---|---|---|---|---|---|")
+    for r in rows[:60]:
+        n, g, cnt, tot, mn = r[0], r[1:1 + len(gcols)], r[-3], r[-2], r[-1]
+        short = re.sub(r"\(.*", "", n)[:70]
+        print(f"| {short} | {'x'.join(str(v) for v in g)} | {cnt/steps:.1f} | {tot/cnt/1e3:.1f} | {mn/1e3:.1f} | {tot/1e6/steps:.3f} |")
