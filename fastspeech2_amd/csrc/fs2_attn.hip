@@ -198,11 +198,21 @@ __device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* row, int
     }
 }
 
+// Register-staged prefetch of a [64 rows][128] bf16 tile (256 threads: 4 x 16 B per thread).  Rows are CLAMPED to the
+// sequence's last row instead of zero-filled: every consumer already multiplies rows >= len by an exact 0 probability /
+// score gradient, so only finiteness matters, and the load needs no predicate (r01h: the synchronous
+// load -> ds_write -> barrier staging left the MFMA pipe idle for the whole L2 round trip of every tile).
+#define TILE_LD1(t, base, ld_, row0, last_row, I) \
+    (t##I) = *reinterpret_cast<const uint4*>((base) + (size_t)min((row0) + ((tid + 256 * I) >> 4), (last_row)) * (ld_) + (tid & 15) * 8)
+#define TILE_LOAD_REGS(t, base, ld_, row0, last_row) do { TILE_LD1(t, base, ld_, row0, last_row, 0); TILE_LD1(t, base, ld_, row0, last_row, 1); \
+    TILE_LD1(t, base, ld_, row0, last_row, 2); TILE_LD1(t, base, ld_, row0, last_row, 3); } while (0)
+#define TILE_ST1(lds, t, I) *reinterpret_cast<uint4*>((lds) + swzb((tid + 256 * I) >> 4, tid & 15)) = (t##I)
+#define TILE_STORE_REGS(lds, t) do { TILE_ST1(lds, t, 0); TILE_ST1(lds, t, 1); TILE_ST1(lds, t, 2); TILE_ST1(lds, t, 3); } while (0)
+
 __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
                                                                long ldo, float* __restrict__ lse,
                                                                const int32_t* __restrict__ lens, int S, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 256];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int len = lens ? min(lens[b], S) : S;
@@ -231,11 +241,21 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
         for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    for (int k0 = 0; k0 < len; k0 += 64) {
-        __syncthreads();
-        stage_tile_bf16<256, 64>(sK, K, ld, k0, min(64, S - k0), tid);
-        stage_tile_bf16<256, 64>(sV, V, ld, k0, min(64, S - k0), tid);
-        __syncthreads();
+    uint4 tk0, tk1, tk2, tk3, tv0, tv1, tv2, tv3;
+    TILE_LOAD_REGS(tk, K, ld, 0, S - 1);
+    TILE_LOAD_REGS(tv, V, ld, 0, S - 1);
+    TILE_STORE_REGS(sKV[0][0], tk);
+    TILE_STORE_REGS(sKV[0][1], tv);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
+        const bool more = k0 + 64 < len;
+        if (more) {                                       // next tile travels while this one is multiplied
+            TILE_LOAD_REGS(tk, K, ld, k0 + 64, S - 1);
+            TILE_LOAD_REGS(tv, V, ld, k0 + 64, S - 1);
+        }
+        const unsigned char* sK = sKV[buf][0];
+        const unsigned char* sV = sKV[buf][1];
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -284,6 +304,11 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
                 for (int nb = 0; nb < 4; ++nb)
                     o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t(sV, kb * 32 + 16 * u, nb, lane), o[nb], 0, 0, 0);
             }
+        if (more) {
+            TILE_STORE_REGS(sKV[buf ^ 1][0], tk);
+            TILE_STORE_REGS(sKV[buf ^ 1][1], tv);
+        }
+        __syncthreads();
     }
     float linv = l > 0.f ? 1.f / l : 0.f;
     if (h2 == 0 && myq < S) lse_o[myq] = (l > 0.f) ? m + __logf(l) : 0.f;
@@ -304,8 +329,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
                                                                    bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,
                                                                    int S, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char sQ[64 * 256];
-    __shared__ __attribute__((aligned(16))) unsigned char sdO[64 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sQD[2][2][64 * 256];   // [buffer][Q | dO]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
     const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int len = lens ? min(lens[b], S) : S;
@@ -340,11 +364,21 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[nb][r] = 0.f; dv[nb][r] = 0.f; }
 
-    for (int q0 = 0; q0 < len; q0 += 64) {
-        __syncthreads();
-        stage_tile_bf16<256, 64>(sQ, Q, ld, q0, min(64, S - q0), tid);
-        stage_tile_bf16<256, 64>(sdO, dO, ldo, q0, min(64, S - q0), tid);
-        __syncthreads();
+    uint4 tq0, tq1, tq2, tq3, td0, td1, td2, td3;
+    TILE_LOAD_REGS(tq, Q, ld, 0, S - 1);
+    TILE_LOAD_REGS(td, dO, ldo, 0, S - 1);
+    TILE_STORE_REGS(sQD[0][0], tq);
+    TILE_STORE_REGS(sQD[0][1], td);
+    __syncthreads();
+    int buf = 0;
+    for (int q0 = 0; q0 < len; q0 += 64, buf ^= 1) {
+        const bool more = q0 + 64 < len;
+        if (more) {
+            TILE_LOAD_REGS(tq, Q, ld, q0 + 64, S - 1);
+            TILE_LOAD_REGS(td, dO, ldo, q0 + 64, S - 1);
+        }
+        const unsigned char* sQ = sQD[buf][0];
+        const unsigned char* sdO = sQD[buf][1];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             if (q0 + qb * 32 >= len) break;
@@ -377,6 +411,11 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
                 }
             }
         }
+        if (more) {
+            TILE_STORE_REGS(sQD[buf ^ 1][0], tq);
+            TILE_STORE_REGS(sQD[buf ^ 1][1], td);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -396,8 +435,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,
                                                                   int S, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 256];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int len = lens ? min(lens[b], S) : S;
@@ -428,11 +466,21 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[nb][r] = 0.f;
 
-    for (int k0 = 0; k0 < len; k0 += 64) {
-        __syncthreads();
-        stage_tile_bf16<256, 64>(sK, K, ld, k0, min(64, S - k0), tid);
-        stage_tile_bf16<256, 64>(sV, V, ld, k0, min(64, S - k0), tid);
-        __syncthreads();
+    uint4 tk0, tk1, tk2, tk3, tv0, tv1, tv2, tv3;
+    TILE_LOAD_REGS(tk, K, ld, 0, S - 1);
+    TILE_LOAD_REGS(tv, V, ld, 0, S - 1);
+    TILE_STORE_REGS(sKV[0][0], tk);
+    TILE_STORE_REGS(sKV[0][1], tv);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
+        const bool more = k0 + 64 < len;
+        if (more) {
+            TILE_LOAD_REGS(tk, K, ld, k0 + 64, S - 1);
+            TILE_LOAD_REGS(tv, V, ld, k0 + 64, S - 1);
+        }
+        const unsigned char* sK = sKV[buf][0];
+        const unsigned char* sV = sKV[buf][1];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (k0 + kb * 32 >= len) break;
@@ -463,6 +511,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                     dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_t(sK, kb * 32 + 16 * u, nb, lane), dq[nb], 0, 0, 0);
             }
         }
+        if (more) {
+            TILE_STORE_REGS(sKV[buf ^ 1][0], tk);
+            TILE_STORE_REGS(sKV[buf ^ 1][1], tv);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -311,14 +311,17 @@ struct BnArgs {
 };
 
 // MODE 0: statistics   1: apply   2: backward pass 1 (sums)   3: backward pass 2 (dx)
-template <typename T, int MODE>
-__global__ void __launch_bounds__(256) bn_rows_kernel(BnArgs a) {
-    __shared__ float s_red[2][256 * 4];
+// Reducing modes (0, 2) run FEW fat workgroups (NT = 1024 threads, 4 rows in flight per thread): every workgroup ends with
+// 2C same-address atomics that all land on the same ~32 cache lines, so their number - not the streaming - sets the time
+// (1024 workgroups: 103-118 us per pass; ~100: the HBM time).  Streaming modes (1, 3) use many 256-thread workgroups.
+template <typename T, int MODE, int NT>
+__global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
+    __shared__ float s_red[2][NT * 4];
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* dout = reinterpret_cast<const T*>(a.dout);
     const T* res = reinterpret_cast<const T*>(a.res);
     T* out = reinterpret_cast<T*>(a.out);
-    const int chunk = threadIdx.x & (a.cprp - 1), rl = threadIdx.x / a.cprp, nrl = 256 / a.cprp;
+    const int chunk = threadIdx.x & (a.cprp - 1), rl = threadIdx.x / a.cprp, nrl = NT / a.cprp;
     const int c = chunk * 4;
     const bool cok = c < a.C;
     uint64_t seed = a.seed;
@@ -339,39 +342,55 @@ __global__ void __launch_bounds__(256) bn_rows_kernel(BnArgs a) {
     }
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
     const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
-    if (cok)
-        for (int r = r0 + rl; r < r1; r += nrl) {
-            const size_t e = (size_t)r * a.C + c;
-            float4 v4 = ld4<T>(x + e);
-            float v[4] = {v4.x, v4.y, v4.z, v4.w};
-            if (MODE == 0) {
+    auto row = [&](int r, float4 v4, float4 g4) {
+        const size_t e = (size_t)r * a.C + c;
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (MODE == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { float d = v[k] - mu[k]; a1[k] += d; a2[k] += d * d; }
-            } else if (MODE == 1) {
+            for (int k = 0; k < 4; ++k) { float d = v[k] - mu[k]; a1[k] += d; a2[k] += d * d; }
+        } else if (MODE == 1) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float o = (v[k] - mu[k]) * rs[k] * gm[k] + bt[k];
-                    if (a.act == FS2_ACT_TANH) o = tanhf(o);
-                    if (a.p > 0.f) o *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
-                    v[k] = o;
-                }
-                if (res) { float4 r4 = ld4<T>(res + e); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
-            } else {
-                float4 g4 = ld4<T>(dout + e);
-                float g[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float xh = (v[k] - mu[k]) * rs[k];
-                    float gg = g[k];
-                    if (a.p > 0.f) gg *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
-                    if (a.act == FS2_ACT_TANH) { float t = tanhf(xh * gm[k] + bt[k]); gg *= (1.f - t * t); }
-                    if (MODE == 2) { a1[k] += gg; a2[k] += gg * xh; }
-                    else v[k] = gm[k] * rs[k] * (gg - m1[k] - xh * m2[k]);
-                }
-                if (MODE == 3) st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
+            for (int k = 0; k < 4; ++k) {
+                float o = (v[k] - mu[k]) * rs[k] * gm[k] + bt[k];
+                if (a.act == FS2_ACT_TANH) o = tanhf(o);
+                if (a.p > 0.f) o *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
+                v[k] = o;
             }
+            if (res) { float4 r4 = ld4<T>(res + e); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+            st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
+        } else {
+            float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float xh = (v[k] - mu[k]) * rs[k];
+                float gg = g[k];
+                if (a.p > 0.f) gg *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
+                if (a.act == FS2_ACT_TANH) { float t = tanhf(xh * gm[k] + bt[k]); gg *= (1.f - t * t); }
+                if (MODE == 2) { a1[k] += gg; a2[k] += gg * xh; }
+                else v[k] = gm[k] * rs[k] * (gg - m1[k] - xh * m2[k]);
+            }
+            if (MODE == 3) st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
         }
+    };
+    if (cok) {
+        constexpr int U = (MODE == 0 || MODE == 2) ? 4 : 2;       // rows in flight per thread
+        int r = r0 + rl;
+        for (; r + (U - 1) * nrl < r1; r += U * nrl) {
+            float4 vv[U], gg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                vv[u] = ld4<T>(x + (size_t)(r + u * nrl) * a.C + c);
+                if (MODE >= 2) gg[u] = ld4<T>(dout + (size_t)(r + u * nrl) * a.C + c); else gg[u] = vv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) row(r + u * nrl, vv[u], gg[u]);
+        }
+        for (; r < r1; r += nrl) {
+            float4 v4 = ld4<T>(x + (size_t)r * a.C + c);
+            float4 g4 = MODE >= 2 ? ld4<T>(dout + (size_t)r * a.C + c) : v4;
+            row(r, v4, g4);
+        }
+    }
     if (MODE == 0 || MODE == 2) {                      // reduce over the block's row lanes, then one atomic per channel
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s_red[0][threadIdx.x * 4 + k] = a1[k]; s_red[1][threadIdx.x * 4 + k] = a2[k]; }
@@ -398,23 +417,24 @@ __global__ void bn_stats_fix_kernel(const T* __restrict__ x, float* __restrict__
     stats[C + c] = fmaxf(s2 - s1 * s1 / (float)M, 0.f);
 }
 
-static int bn_geometry(BnArgs& a, int M, int C) {
+static int bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks) {
     int cpr = C / 4, cprp = 1;
     while (cprp < cpr) cprp <<= 1;
     a.cprp = cprp;
     a.M = M; a.C = C;
-    // ~1000 workgroups, each a whole number of row-lane sweeps
-    int nrl = 256 / cprp;
-    int rpb = fs2_cdiv(M, 1024);
+    // ~want_blocks workgroups, each a whole number of row-lane sweeps
+    int nrl = nthreads / cprp;
+    int rpb = fs2_cdiv(M, want_blocks);
     rpb = fs2_cdiv(rpb, nrl) * nrl;
     if (rpb < nrl) rpb = nrl;
     a.rows_per_block = rpb;
     return fs2_cdiv(M, rpb);
 }
-#define BN_LAUNCH(MODE, grid) do { \
-    if (dtype == FS2_F32) bn_rows_kernel<float, MODE><<<grid, 256, 0, stream>>>(a); \
-    else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE><<<grid, 256, 0, stream>>>(a); \
+#define BN_LAUNCH(MODE, NT, grid) do { \
+    if (dtype == FS2_F32) bn_rows_kernel<float, MODE, NT><<<grid, NT, 0, stream>>>(a); \
+    else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE, NT><<<grid, NT, 0, stream>>>(a); \
     else { fs2_set_error("bn: dtype"); return FS2_EDTYPE; } } while (0)
+#define BN_REDUCE_BLOCKS 96
 
 // stats[0..C) = sum, stats[C..2C) = sum of squared deviations  (caller zeroes stats first)
 extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype, hipStream_t stream) {
@@ -422,8 +442,8 @@ extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
     a.x = x; a.sums = stats;
-    int grid = bn_geometry(a, M, C);
-    BN_LAUNCH(0, grid);
+    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS);
+    BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
     else bn_stats_fix_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats, M, C);
     FS2_CHECK_LAUNCH("bn_stats");
@@ -467,8 +487,8 @@ extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* 
     BnArgs a = {};
     a.x = x; a.res = res; a.out = out; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.act = act; a.p = p;
     a.seed = seed; a.seed_dev = seed_dev;
-    int grid = bn_geometry(a, M, C);
-    BN_LAUNCH(1, grid);
+    int grid = bn_geometry(a, M, C, 256, 2048);
+    BN_LAUNCH(1, 256, grid);
     FS2_CHECK_LAUNCH("bn_apply");
     return FS2_OK;
 }
@@ -485,9 +505,10 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     BnArgs a = {};
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
-    int grid = bn_geometry(a, M, C);
-    BN_LAUNCH(2, grid);
-    BN_LAUNCH(3, grid);
+    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS);
+    BN_LAUNCH(2, 1024, grid);
+    grid = bn_geometry(a, M, C, 256, 2048);
+    BN_LAUNCH(3, 256, grid);
     FS2_CHECK_LAUNCH("bn_bwd");
     return FS2_OK;
 }
