@@ -1044,8 +1044,10 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
     const bool ncol_ok = (n0 + sc * 8) < a.N, ccol_ok = (c0 + sc * 8) < a.Cin;
     const int ncol = ncol_ok ? n0 + sc * 8 : 0, ccol = ccol_ok ? c0 + sc * 8 : 0;     // clamped: always addressable
     const bool x5 = wave < 2;                            // halo rows 64..71 are staged by the first 128 threads
-    uint4 ra[4], rb[4], rb4 = make_uint4(0, 0, 0, 0);
-    bool live_next = true;
+    // TWO register stages (prefetch distance 2 K-tiles: a tile's loads get two tile-times - ~2-4 us - to arrive; with
+    // one stage every K-tile waited out the L2/HBM round trip: 2 us per tile against 0.77 us of MFMA work, at ANY split count)
+    uint4 ra[2][4], rb[2][4], rb4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    bool live_t[2] = {false, false};
     const bool do_bias = a.dbias != nullptr && tile_c == 0 && tap0 == 0;     // block-uniform
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // INTERIOR K-tiles (all 64 rows valid, whole halo inside the sequence, full column tiles: 13 of 15 at T = 925) take a
@@ -1057,23 +1059,24 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X);
     const unsigned dy_rs = (unsigned)a.lddy * 2u, x_rs = (unsigned)a.ldx * 2u;      // row strides in bytes
     const bool small = (double)a.M * (double)dy_rs < 4.0e9 && (double)a.M * (double)x_rs < 4.0e9;   // 32-bit byte offsets
-    unsigned okmask = 0;                                 // edge tiles: bit i: ra[i] valid, bit 4+i: rb[i] valid, bit 8: rb4
-    bool edge_next = false;
-    auto load_tile = [&](int u) {
+    unsigned okmask_t[2] = {0, 0};                       // edge tiles: bit i: ra[i] valid, bit 4+i: rb[i] valid, bit 8: rb4
+    bool edge_t[2] = {false, false};
+    auto load_tile = [&](auto setc, int u) {
+        constexpr int SET = decltype(setc)::value;
         int seq = u / tps, t0 = (u - seq * tps) * 64;
         const int tend = a.lens ? min(a.lens[seq], a.S) : a.S;      // rows >= tend carry zero gradient
-        live_next = t0 < tend;
-        if (!live_next) return;                          // block-uniform: a dead K-tile is neither fetched nor multiplied
+        live_t[SET] = t0 < tend;
+        if (!live_t[SET]) return;                          // block-uniform: a dead K-tile is neither fetched nor multiplied
         const int row0 = seq * a.S + t0;                 // < M: fits 32 bits
-        edge_next = !col_full || !small || (t0 + 64 > tend) || (t0 + shift0 < 0) || (t0 + shift0 + XROWS > a.S);
-        if (!edge_next) {
+        edge_t[SET] = !col_full || !small || (t0 + 64 > tend) || (t0 + shift0 < 0) || (t0 + shift0 + XROWS > a.S);
+        if (!edge_t[SET]) {
             const unsigned o = (unsigned)(row0 + sr) * dy_rs + (unsigned)ncol * 2u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(dYb + (o + (unsigned)(16 * i) * dy_rs));
+            for (int i = 0; i < 4; ++i) ra[SET][i] = *reinterpret_cast<const uint4*>(dYb + (o + (unsigned)(16 * i) * dy_rs));
             const unsigned ox = (unsigned)(row0 + shift0 + sr) * x_rs + (unsigned)ccol * 2u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const uint4*>(Xb + (ox + (unsigned)(16 * i) * x_rs));
-            if (x5) rb4 = *reinterpret_cast<const uint4*>(Xb + (ox + 64u * x_rs));
+            for (int i = 0; i < 4; ++i) rb[SET][i] = *reinterpret_cast<const uint4*>(Xb + (ox + (unsigned)(16 * i) * x_rs));
+            if (x5) rb4[SET] = *reinterpret_cast<const uint4*>(Xb + (ox + 64u * x_rs));
             return;
         }
         size_t base = (size_t)seq * a.S;
@@ -1081,41 +1084,43 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int t = t0 + sr + 16 * i;
-            ra[i] = *reinterpret_cast<const uint4*>(dY + (base + min(t, a.S - 1)) * a.lddy + ncol);
+            ra[SET][i] = *reinterpret_cast<const uint4*>(dY + (base + min(t, a.S - 1)) * a.lddy + ncol);
             ok |= (ncol_ok && t < tend) ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int t = t0 + shift0 + sr + 16 * i;
-            rb[i] = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
+            rb[SET][i] = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
             ok |= (ccol_ok && t >= 0 && t < a.S) ? (16u << i) : 0u;
         }
         if (x5) {                                        // wave-uniform
             int t = t0 + shift0 + sr + 64;
-            rb4 = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
+            rb4[SET] = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
             ok |= (ccol_ok && t >= 0 && t < a.S) ? 256u : 0u;
         }
-        okmask = ok;
+        okmask_t[SET] = ok;
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto setc, int buf) {
+        constexpr int SET = decltype(setc)::value;
+        const unsigned okmask = okmask_t[SET];
         unsigned char* As = smem + buf * (A_BYTES + X_BYTES);
         unsigned char* Bs = As + A_BYTES;
-        if (edge_next) {                                 // block-uniform
+        if (edge_t[SET]) {                               // block-uniform
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = and4(ra[i], 0u - ((okmask >> i) & 1u));
+            for (int i = 0; i < 4; ++i) ra[SET][i] = and4(ra[SET][i], 0u - ((okmask >> i) & 1u));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb[i] = and4(rb[i], 0u - ((okmask >> (4 + i)) & 1u));
-            rb4 = and4(rb4, 0u - ((okmask >> 8) & 1u));
+            for (int i = 0; i < 4; ++i) rb[SET][i] = and4(rb[SET][i], 0u - ((okmask >> (4 + i)) & 1u));
+            rb4[SET] = and4(rb4[SET], 0u - ((okmask >> 8) & 1u));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + wg_swz(sr + 16 * i, sc)) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + wg_swz(sr + 16 * i, sc)) = ra[SET][i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 16 * i, sc)) = rb[i];
-        if (x5) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 64, sc)) = rb4;
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 16 * i, sc)) = rb[SET][i];
+        if (x5) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 64, sc)) = rb4[SET];
         if (do_bias) {                                   // bias gradient rides on the dY tile already in registers
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t* u32 = reinterpret_cast<const uint32_t*>(&ra[i]);
+                const uint32_t* u32 = reinterpret_cast<const uint32_t*>(&ra[SET][i]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bsum[2 * e] += __uint_as_float(u32[e] << 16);
@@ -1181,16 +1186,22 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
                     acc[t][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, af[set][mb]), __builtin_bit_cast(bf16x8, bf[set][t][nb]), acc[t][mb][nb], 0, 0, 0);
     };
-    load_tile(ubeg);
-    if (live_next) store_tile(0);
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    // tile u lives in LDS buffer (u - ubeg) & 1 while it is multiplied; tile u+1 waits in register stage ((u+1-ubeg) & 1),
+    // tile u+2 is being fetched into stage ((u-ubeg) & 1) (whose previous content, tile u, went to LDS one step earlier).
+    load_tile(I0{}, ubeg);
+    if (ubeg + 1 < uend) load_tile(I1{}, ubeg + 1);
+    bool live_lds[2] = {live_t[0], false};
+    if (live_t[0]) store_tile(I0{}, 0);
     __syncthreads();
     // one K-tile out of LDS buffer BUF (compile-time, so every ds_read offset is an immediate)
     auto ktile = [&](auto bufc, int u) {
         constexpr int BUF = decltype(bufc)::value;
         constexpr int bufoff = BUF * (A_BYTES + X_BYTES);
-        const bool live = live_next && !(a.dbg & 2);
+        const bool live = live_lds[BUF] && !(a.dbg & 2);
         if (live) read_frags(0, bufoff, 0);
-        if (u + 1 < uend) load_tile(u + 1); else live_next = false;
+        if (u + 2 < uend) load_tile(std::integral_constant<int, BUF>{}, u + 2); else live_t[BUF] = false;
         if (live) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -1198,12 +1209,15 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
                 mma(ks & 1);
             }
         }
-        if (live_next) store_tile(BUF ^ 1);
+        // tile u+1 (stage BUF^1, fetched one step ago) -> the other LDS buffer
+        const bool nxt = (u + 1 < uend) && live_t[BUF ^ 1];
+        live_lds[BUF ^ 1] = nxt;
+        if (nxt) store_tile(std::integral_constant<int, BUF ^ 1>{}, BUF ^ 1);
         __syncthreads();
     };
     for (int u = ubeg; u < uend; u += 2) {
-        ktile(std::integral_constant<int, 0>{}, u);
-        if (u + 1 < uend) ktile(std::integral_constant<int, 1>{}, u + 1);
+        ktile(I0{}, u);
+        if (u + 1 < uend) ktile(I1{}, u + 1);
     }
     if (a.dbg & 1) return;
     const int fl = lane & 31, fh = lane >> 5;
@@ -1262,10 +1276,18 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     long tiles = (long)fs2_cdiv(a.N, 128) * fs2_cdiv(a.Cin, 128) * groups;
     int tps = (a.S + 63) / 64;
     long units = (long)(a.M / a.S) * tps;
-    static const int wg_target = [] { const char* e = getenv("FS2_WGRAD_WGS"); return e ? atoi(e) : 768; }();
-    long want = (wg_target + tiles - 1) / tiles;        // split-K depth: total workgroups ~ wg_target
+    // Split-K depth.  Every split ends with a full-tile burst of fp32 atomics (~2 TB/s, all CUs at once) and every
+    // workgroup pays ~10 us of prologue/epilogue, so the depth is bounded from both sides (r01h sweep, tools/bench_wgrad.py):
+    //   short reductions (encoder, 96 K-tiles)  -> ~192 workgroups;  1-tap GEMMs (2 workgroups per CU) -> ~384;  else ~768;
+    //   and at least 8 (1-tap) / 16 (few-tile conv) K-tiles per workgroup when the reduction is long.
+    static const int wg_env = [] { const char* e = getenv("FS2_WGRAD_WGS"); return e ? atoi(e) : 0; }();
+    static const int ups_env = [] { const char* e = getenv("FS2_WGRAD_MINUPS"); return e ? atoi(e) : 0; }();
+    int wg_target = units < 256 ? 192 : (NT == 1 ? 384 : 768);
+    int min_ups = NT == 1 ? 8 : ((tiles <= 8 && units >= 512) ? 16 : 4);
+    if (wg_env) wg_target = wg_env;
+    if (ups_env) min_ups = ups_env;
+    long want = (wg_target + tiles - 1) / tiles;
     long ups = (units + want - 1) / want;
-    static const int min_ups = [] { const char* e = getenv("FS2_WGRAD_MINUPS"); return e ? atoi(e) : 4; }();
     if (ups < min_ups) ups = min_ups;
     a.rows_per_split = (int)ups;
     dim3 grid((unsigned)tiles, (unsigned)fs2_cdiv(units, ups));

@@ -166,8 +166,8 @@ class TextDataset(torch.utils.data.Dataset):
 class BucketedBatchSampler:
     """Per-rank list of index lists for one epoch.  The global index list is shuffled (seed + epoch), cut into
     windows of `window` = group_size * world * batch_size items (the reference sorts inside windows of 4 batches,
-    train.py:30-37), each window is sorted by length and its consecutive batch_size-chunks are dealt to the ranks:
-    every rank sees batches of similar length in the same step.  Incomplete last windows are dropped (drop_last)."""
+    train.py:30-37), each window is sorted by length, cut into steps of world*batch_size items, and each step is
+    dealt to the ranks card-wise: every rank sees the same length profile in the same step.  Incomplete last windows are dropped (drop_last)."""
 
     def __init__(self, lengths, batch_size, world_size=1, rank=0, group_size=4, shuffle=True, seed=1234):
         self.lengths = np.asarray(lengths)
@@ -192,7 +192,9 @@ class BucketedBatchSampler:
             w = w[: len(w) // per_step * per_step]
             w = w[np.argsort(-self.lengths[w], kind="stable")]
             for s0 in range(0, len(w), per_step):
-                yield w[s0 + self.rank * self.batch_size: s0 + (self.rank + 1) * self.batch_size].tolist()
+                # strided deal: rank r takes items r, r+world, ... of the step's sorted slice -> every rank sees the same
+                # length profile (and nearly the same longest item, which is what sets its padded T)
+                yield w[s0 + self.rank: s0 + per_step: self.world].tolist()
 
 
 # ---------------------------------------------------------------------------------------------------- H2D prefetch

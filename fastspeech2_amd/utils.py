@@ -142,3 +142,47 @@ def synth_samples(targets, predictions, vocoder, model_config, preprocess_config
         for wav, basename in zip(wavs, basenames):
             wavfile.write(os.path.join(path, "{}.wav".format(basename)), sr, wav)
     return wavs
+
+
+def synth_one_sample(targets, predictions, vocoder, model_config, preprocess_config):
+    """utils/tools.py:107-162 without the matplotlib figure: vocode the first utterance of a train batch from its
+    ground-truth mel and from the predicted post-net mel.  Returns (None, wav_reconstruction, wav_prediction, basename)."""
+    basename = targets[0][0]
+    mel_len = int(predictions[9][0].item())
+    mel_target = targets[6][0, :mel_len].detach().float().transpose(0, 1)
+    mel_prediction = predictions[1][0, :mel_len].detach().float().transpose(0, 1)
+    if vocoder is None:
+        return None, None, None, basename
+    wav_reconstruction = vocoder_infer(mel_target.unsqueeze(0).contiguous(), vocoder, model_config, preprocess_config)[0]
+    wav_prediction = vocoder_infer(mel_prediction.unsqueeze(0).contiguous(), vocoder, model_config, preprocess_config)[0]
+    return None, wav_reconstruction, wav_prediction, basename
+
+
+class RunLogger:
+    """What train.py / evaluate.py need from utils/tools.py:68-88's `log`: scalar losses per step (+ optional audio).
+    TensorBoard is used when importable (it is absent from this image); a `log.jsonl` next to the reference's
+    `log.txt` is always written so runs can be inspected without it."""
+
+    LOSS_NAMES = ("total_loss", "mel_loss", "mel_postnet_loss", "pitch_loss", "energy_loss", "duration_loss")
+
+    def __init__(self, path):
+        os.makedirs(path, exist_ok=True)
+        self.path = path
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.tb = SummaryWriter(path)
+        except Exception:
+            self.tb = None
+
+    def log(self, step=None, losses=None, audio=None, sampling_rate=22050, tag=""):
+        if losses is not None:
+            with open(os.path.join(self.path, "log.jsonl"), "a") as f:
+                f.write(json.dumps({"step": step, **{n: float(v) for n, v in zip(self.LOSS_NAMES, losses)}}) + "\n")
+            if self.tb is not None:
+                for n, v in zip(self.LOSS_NAMES, losses):
+                    self.tb.add_scalar("Loss/" + n, float(v), step)
+        if audio is not None:
+            from scipy.io import wavfile
+            wavfile.write(os.path.join(self.path, tag.replace("/", "_") + ".wav"), sampling_rate, audio)
+            if self.tb is not None:
+                self.tb.add_audio(tag, audio / max(abs(audio).max(), 1), sample_rate=sampling_rate)

@@ -38,3 +38,39 @@ def oracle_train_case(pcfg, mcfg, sd, b, dtype=torch.float32):
 def grad_stats(g):
     g = g.double()
     return np.array([g.sum().item(), g.abs().sum().item(), g.norm().item()])
+
+
+_PHONES = ("AA1 AE0 AH0 AO1 B CH D DH EH1 ER0 F G HH IH1 IY0 JH K L M N NG OW1 P R S SH T TH UW1 V W Y Z sp".split())
+
+
+def make_preprocessed_dir(root, seed=77, n_train=11, n_val=5, n_mel=80, speakers=("LJSpeech",), lo=5, hi=24):
+    """A tiny synthetic dataset in the reference's on-disk format (preprocessor/preprocessor.py:120-161 writes exactly
+    these files): {train,val}.txt lines `name|speaker|{phones}|raw`, speakers.json, stats.json and per-utterance
+    mel/pitch/energy/duration .npy files (phoneme-level pitch/energy).  Deterministic in (seed, sizes)."""
+    import json
+    import os
+
+    rng = np.random.default_rng(seed)
+    for k in ("mel", "pitch", "energy", "duration"):
+        os.makedirs(os.path.join(root, k), exist_ok=True)
+    with open(os.path.join(root, "speakers.json"), "w") as f:
+        json.dump({s: i for i, s in enumerate(speakers)}, f)
+    with open(os.path.join(root, "stats.json"), "w") as f:
+        json.dump(configs.LJ_STATS, f)
+    for fname, n in (("train.txt", n_train), ("val.txt", n_val)):
+        lines = []
+        for i in range(n):
+            name = f"{fname[:2]}{i:03d}"
+            spk = speakers[int(rng.integers(len(speakers)))]
+            L = int(rng.integers(lo, hi + 1))
+            ph = [_PHONES[int(j)] for j in rng.integers(0, len(_PHONES), L)]
+            dur = rng.integers(1, 7, L).astype(np.int64)
+            T = int(dur.sum())
+            np.save(os.path.join(root, "mel", f"{spk}-mel-{name}.npy"), rng.normal(-5, 2, (T, n_mel)).astype(np.float32))
+            np.save(os.path.join(root, "pitch", f"{spk}-pitch-{name}.npy"), rng.normal(0, 1, L))
+            np.save(os.path.join(root, "energy", f"{spk}-energy-{name}.npy"), rng.normal(0, 1, L).astype(np.float32))
+            np.save(os.path.join(root, "duration", f"{spk}-duration-{name}.npy"), dur)
+            lines.append(f"{name}|{spk}|{{{' '.join(ph)}}}|utterance number {i}")
+        with open(os.path.join(root, fname), "w", encoding="utf-8") as f:
+            f.write("\n".join(lines) + "\n")
+    return root
