@@ -37,7 +37,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--phonemes", type=int, default=128)
-    ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (1 GPU)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: replay the train step from a hipGraph.  Default 0 (eager): weight gradients run on a side HIP stream "
+                         "concurrently with the data-gradient chain, which the graph executor serialises (r01i A/B: 12.8 vs 14.2 ms)")
+    ap.add_argument("--host-time", action="store_true", help="also report the host-side issue time of one step (no device sync)")
     ap.add_argument("--mode", default="train", choices=["train", "synth"],
                     help="train: mel-frames/s of the train step (default, the driver's metric); synth: batch-synthesis RTF")
     ap.add_argument("--synth-batch", type=int, default=8, help="utterances per synthesis batch (synthesize.py:199 uses 8)")
@@ -278,6 +281,14 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    host_ms = None
+    if args.host_time and graph is None:
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for _ in range(5):
+            run_step()
+        host_ms = (time.perf_counter() - h0) / 5 * 1e3        # time to ISSUE a step (the device is still running)
+        torch.cuda.synchronize()
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     frames = b["mel_lens"].sum().to(torch.float64)
     padded = torch.tensor([float(args.batch * b["max_mel_len"])], device=device, dtype=torch.float64)
@@ -292,11 +303,15 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         # instrumented eager replay of the same step: HIP events around every conv_gemm launch on its stream
+        # (single stream for this replay: a kernel's event-bracketed duration is only its own when nothing runs beside it)
+        side = model._engine.use_side_stream
+        model._engine.use_side_stream = False
         ops.PROFILE = {}
         for _ in range(3):
             step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        model._engine.use_side_stream = side
         rec = prof.get("conv_gemm", [])
         ms = sum(e0.elapsed_time(e1) for (_, e0, e1) in rec)
         fl = sum(f for (f, _, _) in rec)
@@ -329,7 +344,8 @@ def main():
                                    f"batch={args.batch}/GPU, L={args.phonemes} phonemes, T={b['max_mel_len']} frames, "
                                    "fwd+loss+bwd+clip+Adam, dropout on, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
-                       "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4)},
+                       "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),
+                       "side_stream_wgrad": bool(model._engine.use_side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -46,6 +46,11 @@ class Engine:
         self.Bf = dict(model.named_buffers())
         self.G = None   # name -> grad view (built lazily)
         self.grad_hook = None   # callable(end_offset): flat_grad[0:end_offset) is final (see ddp.GradExchange.ready)
+        import os
+        self.use_side_stream = os.environ.get("FS2_SIDE_STREAM", "1") != "0"
+        self._side_stream = None
+        self._side = None
+        self._side_keep = []
 
     # ------------------------------------------------------------------ weights
     def _flat_view(self, first_name, numel, shape, grad=False):
@@ -167,6 +172,7 @@ class Engine:
 
     def _ready(self, next_name):
         if self.grad_hook is not None:
+            self._side_join()                   # the prefix must be final on the stream the exchange synchronises with
             self.grad_hook(self.m._flat_offsets[next_name] if next_name else self.m._flat.numel())
 
     # ------------------------------------------------------------------ building blocks
@@ -180,9 +186,36 @@ class Engine:
         return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens)
 
     def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0, lens=None):
+        """weight (+ bias) gradient of one contraction.  Weight gradients are OFF the critical path of backward (nothing
+        downstream reads them until the optimiser), so they are issued on a side HIP stream: they fill the CUs that the
+        data-gradient chain's kernels leave idle in their last partial round of workgroups (e.g. the k=9 data gradient runs
+        348 one-per-CU workgroups = 1.36 rounds) and overlap the chain's small latency-bound launches."""
         if gw.dim() == 3:
             gw = gw.permute(0, 2, 1)            # tap-major storage of the gradient
-        ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
+        side = self._side
+        if side is None:
+            ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
+            return
+        side.wait_stream(torch.cuda.current_stream())          # dy was produced on the main stream
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
+        self._side_keep.append((dy, x))         # the caching allocator must not recycle them before the join
+
+    def _side_begin(self):
+        """fork: weight gradients of this backward go to the side stream (FS2_SIDE_STREAM=0 keeps one stream)."""
+        self._side_keep = []
+        if not self.use_side_stream:
+            self._side = None
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        self._side = self._side_stream
+
+    def _side_join(self):
+        """join: everything queued on the side stream happens-before whatever the main stream does next."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._side_keep = []
 
     def _fft_fwd(self, W, pre, x, lens, B, S, n_head, p, seed_dev, site, keep):
         ks = self.tc["conv_kernel_size"]
@@ -430,6 +463,7 @@ class Engine:
             m.attach_grads()
         W, B, L, T, seed_dev = sv.W, sv.B, sv.L, sv.T, sv.seed_dev
         n_mel = P["mel_linear.weight"].shape[0]
+        self._side_begin()
 
         def to_c(t, shape):
             if t is None:
@@ -499,6 +533,8 @@ class Engine:
             dx = self._fft_bwd(W, G, f"encoder.layer_stack.{i}.", sv.enc[i], dx, sv.src_lens32, B, L, n_head, seed_dev)
         self._ready("encoder.src_word_emb.weight")
         ops.embed_bwd(sv.texts, dx, G["encoder.src_word_emb.weight"], pad_idx=0)
+        self._side_join()
+        self._side = None
         self._ready(None)
 
 
