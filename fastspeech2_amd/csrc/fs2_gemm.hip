@@ -38,6 +38,7 @@ struct ConvGemmArgs {
     int in_act; float in_slope;    // activation applied to X on load (leaky-relu prologue of HiFi-GAN)
     int accumulate; float out_scale;
     int vec_ok;                    // Y / R rows are 16-byte addressable (ld % elems-per-16B == 0, aligned bases)
+    int dbg;                       // dev ablations (FS2_GEMM_DBG): 1 = loaders issue no DMA, 2 = consumers issue no MFMA
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -48,6 +49,23 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
         default: return v;
     }
 }
+
+// activation with the kind fixed at COMPILE time.  The epilogues run it on 64-128 accumulators per lane in fully unrolled
+// loops; with the run-time switch above every one of those elements carried its own scalar branch ladder plus an inlined
+// tanhf (the 256x128 kernel grew to ~17 k instructions, far beyond the instruction cache, and its epilogue cost ~8 us per
+// workgroup: r01i ablation 277 us with / 212 us without epilogue on the k=9 FFN conv).  Now the switch runs ONCE per
+// epilogue and selects a straight-line instantiation.
+template <int ACT> __device__ __forceinline__ float act_ct(float v, float slope) {
+    if (ACT == FS2_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == FS2_ACT_TANH) return tanhf(v);
+    if (ACT == FS2_ACT_LRELU) return v > 0.f ? v : v * slope;
+    return v;                                            // none / gate (the gate is applied with the residual operand)
+}
+#define FS2_ACT_DISPATCH(act, CALL) do { switch (act) { \
+    case FS2_ACT_RELU: { constexpr int ACT = FS2_ACT_RELU; CALL; } break; \
+    case FS2_ACT_TANH: { constexpr int ACT = FS2_ACT_TANH; CALL; } break; \
+    case FS2_ACT_LRELU: { constexpr int ACT = FS2_ACT_LRELU; CALL; } break; \
+    default: { constexpr int ACT = FS2_ACT_NONE; CALL; } break; } } while (0)
 
 template <typename T> struct MmaTraits;
 template <> struct MmaTraits<float> { static constexpr int EPC = 4; };   // elements per 16-B chunk
@@ -286,21 +304,23 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
     // row segments are written (and the residual / gate operand read) coalesced.
     // C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* tile = reinterpret_cast<float*>(smem);
+    auto stage = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        int cl = wn * 64 + nb * 32 + fl;
-        int n = n0 + cl;
-        float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+        for (int nb = 0; nb < 2; ++nb) {
+            int cl = wn * 64 + nb * 32 + fl;
+            int n = n0 + cl;
+            float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int rl = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = acc[mb][nb][r] + bv;
-                if (a.act != FS2_ACT_GATE) v = apply_act(v, a.act, a.slope);
-                tile[rl * 128 + cl] = v;
-            }
-    }
+                for (int r = 0; r < 16; ++r) {
+                    int rl = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    tile[rl * 128 + cl] = act_ct<ACT>(acc[mb][nb][r] + bv, a.slope);
+                }
+        }
+    };
+    FS2_ACT_DISPATCH(a.act, stage(std::integral_constant<int, ACT>{}));
     __syncthreads();
     gemm_store_tile<T>(a, tile, m0, n0, tid);
 }
@@ -461,21 +481,23 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
     }
 
     float* tile = reinterpret_cast<float*>(smem);
+    auto stage = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        int cl = wn * 64 + nb * 32 + fl;
-        int n = n0 + cl;
-        float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+        for (int nb = 0; nb < 2; ++nb) {
+            int cl = wn * 64 + nb * 32 + fl;
+            int n = n0 + cl;
+            float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int rl = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = acc[mb][nb][r] + bv;
-                if (a.act != FS2_ACT_GATE) v = apply_act(v, a.act, a.slope);
-                tile[rl * 128 + cl] = v;
-            }
-    }
+                for (int r = 0; r < 16; ++r) {
+                    int rl = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    tile[rl * 128 + cl] = act_ct<ACT>(acc[mb][nb][r] + bv, a.slope);
+                }
+        }
+    };
+    FS2_ACT_DISPATCH(a.act, stage(std::integral_constant<int, ACT>{}));
     __syncthreads();
     gemm_store_tile<T>(a, tile, m0, n0, tid);
 }
@@ -555,7 +577,9 @@ __device__ __forceinline__ void ring_loader(const ConvGemmArgs& a, unsigned char
         int n = min(n0 + r, a.N - 1);
         offB[j] = (unsigned)n * (unsigned)(a.ldw * 2) + (unsigned)((lc ^ ((r >> 1) & 7)) << 4);
     }
+    const bool nodma = a.dbg & 1;
     auto load_A = [&](int kc, int buf) {
+        if (nodma) return;
         const unsigned char* base = Xb + (size_t)kc * 128;
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
@@ -564,6 +588,7 @@ __device__ __forceinline__ void ring_loader(const ConvGemmArgs& a, unsigned char
         }
     };
     auto load_B = [&](int kc, int tap, int slot) {
+        if (nodma) return;
         const unsigned char* base = Wb + ((size_t)tap * a.Cin + (size_t)kc * 64) * 2;
         const unsigned d0 = smem_base + C::B_OFF + slot * RING_B_BYTES + lw * 4096;
 #pragma unroll
@@ -640,51 +665,77 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
             vmask[mb] = msk;
         }
     }
-    uint4 af[2][4], bf[2][2];
-    auto read_frags = [&](int set, int kc, int tap, int slot, int j) {
+    // Fragments are fetched in HALF-STEP groups (two 16-wide k-slices = 12 ds_read_b128, 16 MFMAs): the reads of the next
+    // group are issued before the 16 MFMAs (512 cycles) of the current one.
+    // The reads are issued from inline asm and waited for with a hand-counted s_waitcnt, fenced by sched_barrier(0):
+    //   * left to itself the machine scheduler sinks every ds_read down to just above the MFMA that consumes it and the
+    //     software prefetch is gone (r01i ISA: s_waitcnt lgkmcnt(2)/(1)/(0) right behind freshly issued reads inside the
+    //     MFMA runs; ablations: 86 us fixed + 95 us MFMA + 120 us reads ADD UP to the 304 us kernel, nothing overlaps);
+    //   * with the order pinned by sched_barrier alone, the waitcnt-insertion pass still emits lgkmcnt(0) in front of
+    //     every MFMA group (the older group's reads were issued across the loop back edge / the barrier branch), which
+    //     waits for the 12 reads that were JUST issued - the same serialisation.
+    // lgkmcnt counts LDS operations in order: with 12 younger reads allowed in flight, lgkmcnt(12) == "the older group
+    // has landed".  Nothing else in this loop touches lgkmcnt (no SMEM, no LDS stores in consumer waves).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define FS2_DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+    u32x4 af[2][2][4], bf[2][2][2];
+    const unsigned smem_u = lds_addr(smem);
+    auto read_group = [&](int set, int kc, int tap, int slot, int g) {
         const int roff = tap * a.dil;
         const unsigned a_base = (ONE_TAP ? slot : (kc & 1)) * C::A_BYTES + (wm * 128 + roff) * 128;
         const unsigned x = ((fl + roff) >> 1) & 7;         // swizzle key of the physical halo row
-        const unsigned aaddr = a_base + fl * 128 + ((((unsigned)(fh * 4 + j)) ^ x) << 4);
-        const unsigned baddr = C::B_OFF + slot * RING_B_BYTES + boff[j];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bf[set][nb] = *reinterpret_cast<const uint4*>(smem + baddr + nb * 4096);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            af[set][mb] = *reinterpret_cast<const uint4*>(smem + aaddr + mb * 4096);
-            if (MASK && !((vmask[mb] >> tap) & 1u)) af[set][mb] = make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+            const int j = 2 * g + q;
+            const unsigned aaddr = smem_u + a_base + fl * 128 + ((((unsigned)(fh * 4 + j)) ^ x) << 4);
+            const unsigned baddr = smem_u + C::B_OFF + slot * RING_B_BYTES + boff[j];
+            FS2_DS_READ_B128(bf[set][q][0], baddr, 0);
+            FS2_DS_READ_B128(bf[set][q][1], baddr, 4096);
+            FS2_DS_READ_B128(af[set][q][0], aaddr, 0);
+            FS2_DS_READ_B128(af[set][q][1], aaddr, 4096);
+            FS2_DS_READ_B128(af[set][q][2], aaddr, 8192);
+            FS2_DS_READ_B128(af[set][q][3], aaddr, 12288);
         }
     };
-    auto mfma_group = [&](int set) {
+    auto mfma_group = [&](int set, int tap) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(bf16x8, af[set][mb]), __builtin_bit_cast(bf16x8, bf[set][nb]), acc[mb][nb], 0, 0, 0);
+            for (int mb = 0; mb < 4; ++mb) {
+                u32x4 av = af[set][q][mb];
+                if (MASK && !((vmask[mb] >> tap) & 1u)) av = u32x4{0u, 0u, 0u, 0u};     // tap leaves the row's sequence
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bf[set][q][nb]), acc[mb][nb], 0, 0, 0);
+            }
     };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // kernel-argument loads etc. retired: lgkmcnt is ours from here
     __builtin_amdgcn_s_barrier();                          // slot(0) published
-    read_frags(0, 0, 0, 0, 0);
+    read_group(0, 0, 0, 0, 0);
     int slot = 0, step = 0;
     for (int kc = 0; kc < nkc; ++kc) {
         for (int tap = 0; tap < taps; ++tap, ++step) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                read_frags((j + 1) & 1, kc, tap, slot, j + 1);
-                mfma_group(j & 1);
-            }
-            // next step's first fragments are fetched behind ITS barrier while this step's last MFMA group runs
+            read_group(1, kc, tap, slot, 1);
+            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");      // first half (12 older reads) has landed
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, tap);
+            __builtin_amdgcn_sched_barrier(0);
+            // next step's first half is fetched behind ITS barrier while this step's second half runs
             int nslot = slot + 1; if (nslot == D) nslot = 0;
             int ntap = tap + 1, nkc_ = kc; if (ntap == taps) { ntap = 0; ++nkc_; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // second half landed; my reads of slot(step) are done
             if (step + 1 < nsteps) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the slot about to be refilled are done
                 __builtin_amdgcn_s_barrier();
-                read_frags(0, nkc_, ntap, nslot, 0);
+                read_group(0, nkc_, ntap, nslot, 0);
             }
-            mfma_group(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(1, tap);
+            __builtin_amdgcn_sched_barrier(0);
             slot = nslot;
         }
     }
+#undef FS2_DS_READ_B128
 }
 
 template <bool ONE_TAP>
@@ -715,6 +766,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
             return;
         }
     }
+    if (a.dbg & 16) return;
     f32x16 acc[4][2];
     if (wave >= 4) {
         ring_loader<ONE_TAP>(a, smem, m0, n0, lane, wave - 4);
@@ -736,28 +788,32 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
         }
     }
     __syncthreads();                                       // every consumer is done reading the operand slots
+    if (a.dbg & 8) { if (tid == 0 && acc[0][0][0] == 12345.f) Y[0] = 0; return; }
 
     // epilogue: the whole 256x128 f32 tile through LDS (128 KB), written by the consumers, stored by all 8 waves
     float* tile = reinterpret_cast<float*>(smem);
     if (wave < 4) {
         const int fl = lane & 31, fh = lane >> 5;
+        auto stage = [&](auto actc) {
+            constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            int cl = wn * 64 + nb * 32 + fl;
-            int n = n0 + cl;
-            float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+            for (int nb = 0; nb < 2; ++nb) {
+                int cl = wn * 64 + nb * 32 + fl;
+                int n = n0 + cl;
+                float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+                for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int rl = wm * 128 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    float v = acc[mb][nb][r] + bv;
-                    if (a.act != FS2_ACT_GATE) v = apply_act(v, a.act, a.slope);
-                    tile[rl * 128 + cl] = v;
-                }
-        }
+                    for (int r = 0; r < 16; ++r) {
+                        int rl = wm * 128 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        tile[rl * 128 + cl] = act_ct<ACT>(acc[mb][nb][r] + bv, a.slope);
+                    }
+            }
+        };
+        FS2_ACT_DISPATCH(a.act, stage(std::integral_constant<int, ACT>{}));
     }
     __syncthreads();
+    if (a.dbg & 32) { if (tile[tid] == 12345.f) Y[0] = 0; return; }
     gemm_store_tile<bf16_t, 128, 512>(a, tile, m0, n0, tid);
     gemm_store_tile<bf16_t, 128, 512>(a, tile + 128 * 128, m0 + 128, n0, tid);
 }
@@ -778,6 +834,8 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = (long)taps * Cin; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
     a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps; a.dil = dil; a.pad = pad; a.act = act;
     a.slope = slope; a.in_act = in_act; a.in_slope = in_slope; a.accumulate = accumulate; a.out_scale = out_scale;
+    static const int gemm_dbg = [] { const char* e = getenv("FS2_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = gemm_dbg;
     a.vec_ok = (ldy % epc == 0) && (((uintptr_t)Y & 15) == 0) && (!R || ((ldr % epc == 0) && (((uintptr_t)R & 15) == 0)));
     long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     // taps == 1 keeps the register-staged kernel (its 3-stage pipeline wins when there is no halo to reuse)
