@@ -196,14 +196,15 @@ class Engine:
         if side is None:
             ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
             return
-        side.wait_stream(torch.cuda.current_stream())          # dy was produced on the main stream
-        with torch.cuda.stream(side):
+        side.wait_stream(self._main)            # dy was produced on the main stream
+        with ops.pinned_stream(side):           # (no allocation happens inside: only the launch needs the side stream)
             ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
         self._side_keep.append((dy, x))         # the caching allocator must not recycle them before the join
 
     def _side_begin(self):
         """fork: weight gradients of this backward go to the side stream (FS2_SIDE_STREAM=0 keeps one stream)."""
         self._side_keep = []
+        self._main = torch.cuda.current_stream()
         if not self.use_side_stream:
             self._side = None
             return
@@ -214,7 +215,7 @@ class Engine:
     def _side_join(self):
         """join: everything queued on the side stream happens-before whatever the main stream does next."""
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            self._main.wait_stream(self._side)
         self._side_keep = []
 
     def _fft_fwd(self, W, pre, x, lens, B, S, n_head, p, seed_dev, site, keep):
@@ -323,6 +324,10 @@ class Engine:
         return (mel, post, p_pred, e_pred, logd, st.d_rounded, src_masks, mel_masks, src_lens, st.mel_lens_out)
 
     def forward(self, st):
+        with ops.pinned_stream():
+            return self._forward(st)
+
+    def _forward(self, st):
         m, P, cdt, d = self.m, self.P, self.cdt, self.d
         training, keep = st.training, st.need_grad
         W = self.weights(need_dgrad=keep)
@@ -456,6 +461,10 @@ class Engine:
 
     # ------------------------------------------------------------------ whole-model backward
     def backward(self, sv, dmel, dpost, dp, de, dlogd):
+        with ops.pinned_stream():
+            return self._backward(sv, dmel, dpost, dp, de, dlogd)
+
+    def _backward(self, sv, dmel, dpost, dp, de, dlogd):
         m, P, cdt = self.m, self.P, self.cdt
         G = self._grads()
         if any(p.grad is None for p in (P["mel_linear.weight"],)):

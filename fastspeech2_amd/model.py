@@ -210,6 +210,9 @@ class FastSpeech2(nn.Module):
         """(name, param) pairs ordered by when their gradient completes in backward: postnet (last conv first),
         mel_linear, decoder layers N-1..0, variance adaptor, [speaker], encoder layers N-1..0, embedding.
         QKV weights (and biases) are adjacent so the fused [3d, d] projection is one matrix."""
+        cached = getattr(self, "_tibo", None)
+        if cached is not None:
+            return cached
         named = dict(self.named_parameters())
         order = []
 
@@ -241,7 +244,8 @@ class FastSpeech2(nn.Module):
         order.append("encoder.src_word_emb.weight")
         trainable = [n for n, p in named.items() if p.requires_grad]
         assert sorted(order) == sorted(trainable), "flat layout does not cover the trainable parameters"
-        return [(n, named[n]) for n in order]
+        self._tibo = [(n, named[n]) for n in order]      # the parameter set is fixed after construction
+        return self._tibo
 
     def _invalidate(self, lowp_synced=False):
         """parameters changed: the engine must refresh its packed weights (lowp_synced: the bf16 shadow copy of the

@@ -31,8 +31,33 @@ def _p(t):
     return t.data_ptr()
 
 
+_tls = __import__("threading").local()
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """HIP stream handle the next launch goes to.  torch.cuda.current_stream() costs ~8 us per call (r01i host profile:
+    ~3 ms per train step for ~400 launches), so the engine pins the handle for the duration of a forward / backward with
+    `pinned_stream`; outside such a block the current torch stream is looked up per call."""
+    h = getattr(_tls, "handle", None)
+    return h if h is not None else torch.cuda.current_stream().cuda_stream
+
+
+class pinned_stream:
+    """with pinned_stream(): ... — launches inside use the torch stream that is current on ENTRY (or `stream` if given),
+    without further lookups.  Nestable (the side-stream sections of backward nest inside the main one)."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "handle", None)
+        s = self.stream if self.stream is not None else torch.cuda.current_stream()
+        _tls.handle = s.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _tls.handle = self.prev
+        return False
 
 
 def _contig(t):

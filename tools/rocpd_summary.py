@@ -31,3 +31,23 @@ if gcols and len(sys.argv) > 3 and sys.argv[3] == "shapes":
         n, g, cnt, tot, mn = r[0], r[1:1 + len(gcols)], r[-3], r[-2], r[-1]
         short = re.sub(r"\(.*", "", n)[:70]
         print(f"| {short} | {'x'.join(str(v) for v in g)} | {cnt/steps:.1f} | {tot/cnt/1e3:.1f} | {mn/1e3:.1f} | {tot/1e6/steps:.3f} |")
+
+# ---- device occupancy over time: union of all kernel intervals vs the span (idle = launch gaps / host-bound stretches)
+if len(sys.argv) > 3:
+    iv = c.execute("select start, end from kernels order by start").fetchall()
+    if iv:
+        span = max(e for _, e in iv) - iv[0][0]
+        busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+        gaps = []
+        for s0, e0 in iv[1:]:
+            if s0 > cur_e:
+                busy += cur_e - cur_s
+                gaps.append(s0 - cur_e)
+                cur_s, cur_e = s0, e0
+            else:
+                cur_e = max(cur_e, e0)
+        busy += cur_e - cur_s
+        big = sorted(gaps, reverse=True)
+        print(f"\n## timeline\n\nspan {span/1e6:.3f} ms, some kernel running {busy/1e6:.3f} ms ({100*busy/span:.1f} %), idle {(span-busy)/1e6:.3f} ms in {len(gaps)} gaps "
+              f"(gaps > 20 us: {sum(1 for g in gaps if g > 20000)}, their sum {sum(g for g in gaps if g > 20000)/1e6:.3f} ms; "
+              f"gaps 2-20 us: {sum(1 for g in gaps if 2000 < g <= 20000)}, sum {sum(g for g in gaps if 2000 < g <= 20000)/1e6:.3f} ms)")
