@@ -202,14 +202,16 @@ def synth_main(args):
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the roofline kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE, collected in separate runs by tools/pmc_traffic.py; counters cannot be read live here)."""
-    path = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
-    if not os.path.exists(path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not cands:
         return None
+    path = cands[-1]                                      # newest round's passes
     k = json.load(open(path))["kernels"]
     n = sum(v["launches_per_step"] for name, v in k.items() if kernel_substr in name)
     b = sum(v["launches_per_step"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for name, v in k.items()
             if kernel_substr in name)
-    return {"bytes_per_launch": round(b / n), "source": "profiles/r01g_pmc_traffic.json (rocprofv3 --pmc, separate passes)"} if n else None
+    return {"bytes_per_launch": round(b / n), "source": "profiles/%s (rocprofv3 --pmc, separate passes)" % os.path.basename(path)} if n else None
 
 
 def main():

@@ -325,9 +325,29 @@ class FastSpeech2(nn.Module):
                                 float(p_control), float(e_control), float(d_control))
 
 
+class _FusedLoss(torch.autograd.Function):
+    """All five loss terms in one pass over the padded tensors (fs2_loss_fwd), gradients in one more (fs2_loss_bwd)."""
+
+    @staticmethod
+    def forward(ctx, mel, post, p_pred, e_pred, logd, mel_t, mel_lens, src_lens, p_t, e_t, dur, cnt, p_frame, e_frame):
+        mel, post, p_pred, e_pred, logd = (t.contiguous() for t in (mel, post, p_pred, e_pred, logd))
+        losses = ops.loss_fwd(mel, post, mel_t, mel_lens, src_lens, p_pred, p_t, e_pred, e_t, logd, dur, cnt, p_frame, e_frame)
+        ctx.save_for_backward(mel, post, p_pred, e_pred, logd, mel_t, mel_lens, src_lens, p_t, e_t, dur, cnt)
+        ctx.flags = (p_frame, e_frame)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        mel, post, p_pred, e_pred, logd, mel_t, mel_lens, src_lens, p_t, e_t, dur, cnt = ctx.saved_tensors
+        grads = ops.loss_bwd(mel, post, mel_t, mel_lens, src_lens, p_pred, p_t, e_pred, e_t, logd, dur, cnt,
+                             g.contiguous().float(), *ctx.flags)
+        return grads + (None,) * 9
+
+
 class FastSpeech2Loss(nn.Module):
-    """reference model/loss.py:5-92.  Masked means over valid positions; thin elementwise work left to torch
-    device ops (SURVEY §8(f) rank 2 lists the fused-loss kernel as a "next" row)."""
+    """reference model/loss.py:5-92: masked L1 on mel / post-net mel, masked MSE on pitch / energy / log-duration, and
+    their sum, as HIP kernels (fs2_loss.hip) behind one autograd node.  Returns the reference's 6-tuple
+    (total, mel, postnet_mel, pitch, energy, duration) of 0-dim tensors."""
 
     def __init__(self, preprocess_config, model_config, count_reduce=None):
         super().__init__()
@@ -339,30 +359,26 @@ class FastSpeech2Loss(nn.Module):
 
     def forward(self, inputs, predictions):
         mel_targets, _, _, pitch_targets, energy_targets, duration_targets = inputs[6:]
-        (mel_pred, post_pred, pitch_pred, energy_pred, logd_pred, _, src_masks, mel_masks, _, _) = predictions
-        src_v, mel_v = ~src_masks, ~mel_masks
-        logd_t = torch.log(duration_targets.float() + 1)
-        mel_targets = mel_targets[:, : mel_v.shape[1], :]
-        counts = torch.stack([src_v.sum(), mel_v.sum()]).float()
+        (mel_pred, post_pred, pitch_pred, energy_pred, logd_pred, _, src_masks, mel_masks, src_lens, mel_lens) = predictions
+        if not mel_pred.is_cuda:
+            raise RuntimeError("FastSpeech2Loss runs on an AMD GPU only (no CPU fallback)")
+        T, L = mel_pred.shape[1], logd_pred.shape[1]
+        # valid positions exactly as the masks the model returned (utils/tools.py:91-99): t < min(len, padded length)
+        src_lens = src_lens.to(torch.int64)
+        mel_lens = mel_lens.to(torch.int64)
+        counts = torch.stack([src_lens.clamp(max=L).sum(), mel_lens.clamp(max=T).sum()]).float()
         if self.count_reduce is not None:
             counts = self.count_reduce(counts)
-        n_of = {id(src_v): counts[0], id(mel_v): counts[1]}
-
-        def masked_mse(pred, tgt, valid):
-            return (((pred - tgt) ** 2) * valid).sum() / n_of[id(valid)]
-
-        def masked_l1(pred, tgt, valid):
-            return ((pred - tgt).abs() * valid.unsqueeze(-1)).sum() / (n_of[id(valid)] * pred.shape[-1])
-
-        pm = src_v if self.pitch_feature_level == "phoneme_level" else mel_v
-        em = src_v if self.energy_feature_level == "phoneme_level" else mel_v
-        pitch_loss = masked_mse(pitch_pred, pitch_targets, pm)
-        energy_loss = masked_mse(energy_pred, energy_targets, em)
-        duration_loss = masked_mse(logd_pred, logd_t, src_v)
-        mel_loss = masked_l1(mel_pred, mel_targets, mel_v)
-        post_loss = masked_l1(post_pred, mel_targets, mel_v)
-        total = mel_loss + post_loss + duration_loss + pitch_loss + energy_loss
-        return total, mel_loss, post_loss, pitch_loss, energy_loss, duration_loss
+        mel_t = mel_targets if mel_targets.dtype == torch.float32 else mel_targets.float()
+        assert mel_t.shape[1] >= T and mel_t.stride(2) == 1 and mel_t.stride(1) == mel_t.shape[2], "mel targets must be (B, >=T, n_mel) rows"
+        p_t = pitch_targets.float() if pitch_targets.dtype != torch.float32 else pitch_targets
+        e_t = energy_targets.float() if energy_targets.dtype != torch.float32 else energy_targets
+        dur = duration_targets if duration_targets.dtype == torch.int64 else duration_targets.long()
+        assert p_t.stride(1) == 1 and e_t.stride(1) == 1 and dur.stride(1) == 1
+        losses = _FusedLoss.apply(mel_pred, post_pred, pitch_pred, energy_pred, logd_pred, mel_t, mel_lens, src_lens, p_t, e_t,
+                                  dur, counts, self.pitch_feature_level != "phoneme_level",
+                                  self.energy_feature_level != "phoneme_level")
+        return tuple(losses.unbind(0))
 
 
 class ScheduledOptim:

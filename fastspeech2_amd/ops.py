@@ -316,3 +316,27 @@ def add_pe(x, pe, B, S):
 
 def bump_counter(ctr, inc=1):
     _lib.call("fs2_bump_counter", _p(ctr), inc, _stream())
+
+
+# ------------------------------------------------------------------ loss
+def loss_fwd(mel, post, mel_t, mel_lens, src_lens, p_pred, p_t, e_pred, e_t, logd, dur, cnt, p_frame, e_frame):
+    """-> losses[6] (device f32): total, mel, postnet, pitch, energy, duration."""
+    B, T, n_mel = mel.shape
+    L = logd.shape[1]
+    sums = torch.empty(5, device=mel.device, dtype=torch.float32)
+    losses = torch.empty(6, device=mel.device, dtype=torch.float32)
+    _lib.call("fs2_loss_fwd", _p(mel), _p(post), _p(mel_t), mel_t.stride(0), _p(mel_lens), _p(src_lens), _p(p_pred), _p(p_t),
+              p_t.stride(0), _p(e_pred), _p(e_t), e_t.stride(0), _p(logd), _p(dur), dur.stride(0), _p(cnt), B, T, L, n_mel,
+              int(p_frame), int(e_frame), _p(sums), _p(losses), _stream())
+    return losses
+
+
+def loss_bwd(mel, post, mel_t, mel_lens, src_lens, p_pred, p_t, e_pred, e_t, logd, dur, cnt, g, p_frame, e_frame):
+    B, T, n_mel = mel.shape
+    L = logd.shape[1]
+    dmel, dpost = torch.empty_like(mel), torch.empty_like(post)
+    dp, de, dlogd = torch.empty_like(p_pred), torch.empty_like(e_pred), torch.empty_like(logd)
+    _lib.call("fs2_loss_bwd", _p(mel), _p(post), _p(mel_t), mel_t.stride(0), _p(mel_lens), _p(src_lens), _p(p_pred), _p(p_t),
+              p_t.stride(0), _p(e_pred), _p(e_t), e_t.stride(0), _p(logd), _p(dur), dur.stride(0), _p(cnt), _p(g), B, T, L, n_mel,
+              int(p_frame), int(e_frame), _p(dmel), _p(dpost), _p(dp), _p(de), _p(dlogd), _stream())
+    return dmel, dpost, dp, de, dlogd

@@ -161,6 +161,23 @@ int fs2_stft_mel_epilogue(const float* ft, long ldft, const float* mel_basis, co
                           float* energy, int B, int S, int frames, int NF, int n_mel, float clamp_min,
                           fs2_stream_t stream);
 
+/* ---- loss (model/loss.py:19-92): masked L1 (mel, post-net mel) + masked MSE (pitch, energy, log-duration) ----
+ * mel / post: [B][T][n_mel] f32 predictions; mel_t: target with batch stride ld_t_b (its own padded length >= T);
+ * lens int64 (valid = t < min(len, T)); p/e predictions [B][L] (phoneme level) or [B][T] (p_frame / e_frame = 1) with
+ * target row strides ld_pt / ld_et; logd [B][L], dur int64 [B][L] (row stride ld_dur; target = log(dur + 1));
+ * cnt (device) = {valid phonemes, valid frames} = the divisors of the means (data-parallel: global counts / world).
+ * fwd: sums[5] workspace, losses[6] = {total, mel, postnet, pitch, energy, duration}.
+ * bwd: g[6] (device) upstream gradients of the 6 outputs; writes dense gradients (exact zeros on padding). */
+int fs2_loss_fwd(const float* mel, const float* post, const float* mel_t, long ld_t_b, const int64_t* mel_lens,
+                 const int64_t* src_lens, const float* p_pred, const float* p_t, long ld_pt, const float* e_pred,
+                 const float* e_t, long ld_et, const float* logd, const int64_t* dur, long ld_dur, const float* cnt,
+                 int B, int T, int L, int n_mel, int p_frame, int e_frame, float* sums, float* losses, fs2_stream_t stream);
+int fs2_loss_bwd(const float* mel, const float* post, const float* mel_t, long ld_t_b, const int64_t* mel_lens,
+                 const int64_t* src_lens, const float* p_pred, const float* p_t, long ld_pt, const float* e_pred,
+                 const float* e_t, long ld_et, const float* logd, const int64_t* dur, long ld_dur, const float* cnt,
+                 const float* g, int B, int T, int L, int n_mel, int p_frame, int e_frame, float* dmel, float* dpost,
+                 float* dp, float* de, float* dlogd, fs2_stream_t stream);
+
 /* ---- optimiser: train.py:93 clip_grad_norm_ + model/optimizer.py:10-51 Adam ------------------------- */
 int fs2_sumsq(const float* x, size_t n, float* out /*+=*/, fs2_stream_t stream);
 /* hyper (device) = {lr, 1-beta1^t, 1-beta2^t}; clip = min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)).

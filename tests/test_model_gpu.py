@@ -164,3 +164,39 @@ def test_dropout_training_runs_and_optimizer_steps(dev):
     o1 = run_train(model, pcfg, mcfg, b, dev)[0][1]
     o2 = run_train(model, pcfg, mcfg, b, dev)[0][1]
     assert not torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("frame_level", [False, True])
+def test_fused_loss_matches_oracle(dev, frame_level):
+    """fs2_loss_fwd / fs2_loss_bwd vs the oracle's masked_select formulation (model/loss.py:19-92): all six values, and the
+    gradients for a non-trivial combination of the outputs; targets longer than the predictions (cropped batches)."""
+    from fastspeech2_amd.model import FastSpeech2Loss
+    from oracle import fs2_oracle as O
+    torch.manual_seed(11)
+    pcfg, mcfg = configs.make(frame_level=frame_level)
+    B, L, T, Tt = 5, 37, 211, 230
+    src_lens = torch.tensor([37, 30, 22, 9, 1]); mel_lens = torch.tensor([211, 250, 120, 40, 3])     # one un-cropped length > T
+    S = T if frame_level else L
+    preds = [torch.randn(B, T, 80), torch.randn(B, T, 80), torch.randn(B, S), torch.randn(B, S), torch.randn(B, L)]
+    mel_t = torch.randn(B, Tt, 80); p_t = torch.randn(B, Tt if frame_level else L); e_t = torch.randn(B, Tt if frame_level else L)
+    if frame_level:
+        p_t, e_t = p_t[:, :T], e_t[:, :T]                      # non-contiguous views with their own row stride
+    dur = torch.randint(0, 9, (B, L))
+    src_masks = torch.arange(L).unsqueeze(0) >= src_lens.unsqueeze(1)
+    mel_masks = torch.arange(T).unsqueeze(0) >= mel_lens.unsqueeze(1)
+    w = torch.tensor([1.0, 2.0, 0.0, 0.5, 0.0, 3.0])
+
+    def run(device, loss_fn):
+        ps = [p.clone().to(device).requires_grad_(True) for p in preds]
+        out = (*ps, None, src_masks.to(device), mel_masks.to(device), src_lens.to(device), mel_lens.to(device))
+        losses = loss_fn(out, mel_t.to(device), p_t.to(device), e_t.to(device), dur.to(device))
+        sum(wi * li for wi, li in zip(w.tolist(), losses)).backward()
+        return [l.detach().cpu() for l in losses], [p.grad.cpu() for p in ps]
+
+    fused = FastSpeech2Loss(pcfg, mcfg)
+    lv, gv = run(dev, lambda out, m, p, e, d: fused((None,) * 6 + (m, None, None, p, e, d), out))
+    lo, go = run("cpu", lambda out, m, p, e, d: O.fastspeech2_loss(pcfg, (m, p, e, d), out))
+    for a, b in zip(lv, lo):
+        assert abs(a.item() - b.item()) < 2e-6 * max(1.0, abs(b.item()))
+    for a, b in zip(gv, go):
+        assert torch.allclose(a, b, atol=1e-8, rtol=1e-5)
