@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--graph", type=int, default=0,
                     help="1: replay the train step from a hipGraph.  Default 0 (eager): weight gradients run on a side HIP stream "
                          "concurrently with the data-gradient chain, which the graph executor serialises (r01i A/B: 12.8 vs 14.2 ms)")
+    ap.add_argument("--main-prio", type=int, default=-1,
+                    help="priority of the stream the step runs on (-1 = high: the dispatcher prefers the critical fwd/dgrad chain over "
+                         "the side stream's weight gradients; 0 = run on the default stream)")
     ap.add_argument("--host-time", action="store_true", help="also report the host-side issue time of one step (no device sync)")
     ap.add_argument("--mode", default="train", choices=["train", "synth"],
                     help="train: mel-frames/s of the train step (default, the driver's metric); synth: batch-synthesis RTF")
@@ -232,6 +235,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from fastspeech2_amd import ddp, ops
+    if args.main_prio != 0:
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=args.main_prio))
     model, loss_fn, opt, b, pcfg, mcfg = build(args, device, rank, world)
     exchange = None
     if world > 1:

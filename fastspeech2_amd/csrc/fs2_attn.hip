@@ -256,14 +256,26 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
         }
         const unsigned char* sK = sKV[buf][0];
         const unsigned char* sV = sKV[buf][1];
+        // software pipeline over the 8 d-slices: the two K fragments of slice st+1 are in flight while slice st is
+        // multiplied (two independent accumulator chains); sched_barrier pins the order - unpinned, the scheduler sinks
+        // each read to just above its MFMA (r01i ISA: ds_read / s_waitcnt lgkmcnt(0) / v_mfma, 16 times in a row)
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        {
+            bf16x8 c0 = frag_k(sK, fl, 0, h2), c1 = frag_k(sK, 32 + fl, 0, h2);
 #pragma unroll
-            for (int st = 0; st < 8; ++st)
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sK, kb * 32 + fl, st, h2), qf[st], s[kb], 0, 0, 0);
+            for (int st = 0; st < 8; ++st) {
+                bf16x8 n0 = c0, n1 = c1;
+                if (st < 7) { n0 = frag_k(sK, fl, st + 1, h2); n1 = frag_k(sK, 32 + fl, st + 1, h2); }
+                __builtin_amdgcn_sched_barrier(0);
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, qf[st], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, qf[st], s[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = n0; c1 = n1;
+            }
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -292,18 +304,28 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
         }
+        {   // P V: the four V fragments of the next 16-key group are fetched while the current group is multiplied
+            bf16x8 cv[4], nv[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int nb = 0; nb < 4; ++nb) cv[nb] = frag_t(sV, 0, nb, lane);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int g = 0; g < 4; ++g) {                 // g = 2*kb + u: keys 16g .. 16g+15 of the tile
+                if (g < 3) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) nv[nb] = frag_t(sV, 16 * (g + 1), nb, lane);
+                }
                 float pv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = s[kb][8 * u + e];
+                for (int e = 0; e < 8; ++e) pv[e] = s[g >> 1][8 * (g & 1) + e];
                 bf16x8 pa = pack8(pv);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_t(sV, kb * 32 + 16 * u, nb, lane), o[nb], 0, 0, 0);
+                for (int nb = 0; nb < 4; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, cv[nb], o[nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) cv[nb] = nv[nb];
             }
+        }
         if (more) {
             TILE_STORE_REGS(sKV[buf ^ 1][0], tk);
             TILE_STORE_REGS(sKV[buf ^ 1][1], tv);

@@ -92,8 +92,8 @@ extern "C" int fs2_loss_fwd(const float* mel, const float* post, const float* me
     a.p_pred = p_pred; a.p_t = p_t; a.e_pred = e_pred; a.e_t = e_t; a.ld_pt = ld_pt; a.ld_et = ld_et; a.logd = logd; a.dur = dur;
     a.ld_dur = ld_dur; a.B = B; a.T = T; a.L = L; a.n_mel = n_mel; a.p_frame = p_frame; a.e_frame = e_frame; a.sums = sums;
     (void)hipMemsetAsync(sums, 0, 5 * sizeof(float), stream);
-    int bps = fs2_cdiv((long)T * n_mel, 256 * 8);
-    if (bps > 64) bps = 64;
+    int bps = fs2_cdiv((long)T * n_mel, 256 * 32);          // few blocks per sequence: each ends with 2-5 same-address atomics
+    if (bps > 8) bps = 8;
     loss_fwd_kernel<<<dim3(bps, B), 256, 0, stream>>>(a);
     loss_finalize_kernel<<<1, 64, 0, stream>>>(sums, cnt, n_mel, p_frame, e_frame, losses);
     FS2_CHECK_LAUNCH("loss_fwd");

@@ -310,6 +310,14 @@ struct BnArgs {
     float p; uint64_t seed; const uint64_t* seed_dev;
 };
 
+// tanh through one v_exp_f32 and one reciprocal (|error| < 2e-7 absolute; tanhf's branchy polynomial costs ~3x as much
+// and runs three times per PostNet element: forward, backward sums, backward dx)
+__device__ __forceinline__ float fs2_tanh(float x) {
+    float e = __expf(2.f * fabsf(x));
+    float t = 1.f - 2.f / (e + 1.f);              // e = +inf -> 1
+    return copysignf(t, x);
+}
+
 // MODE 0: statistics   1: apply   2: backward pass 1 (sums)   3: backward pass 2 (dx)
 // Reducing modes (0, 2) run FEW fat workgroups (NT = 1024 threads, 4 rows in flight per thread): every workgroup ends with
 // 2C same-address atomics that all land on the same ~32 cache lines, so their number - not the streaming - sets the time
@@ -352,7 +360,7 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float o = (v[k] - mu[k]) * rs[k] * gm[k] + bt[k];
-                if (a.act == FS2_ACT_TANH) o = tanhf(o);
+                if (a.act == FS2_ACT_TANH) o = fs2_tanh(o);
                 if (a.p > 0.f) o *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
                 v[k] = o;
             }
@@ -365,7 +373,7 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
                 float xh = (v[k] - mu[k]) * rs[k];
                 float gg = g[k];
                 if (a.p > 0.f) gg *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
-                if (a.act == FS2_ACT_TANH) { float t = tanhf(xh * gm[k] + bt[k]); gg *= (1.f - t * t); }
+                if (a.act == FS2_ACT_TANH) { float t = fs2_tanh(xh * gm[k] + bt[k]); gg *= (1.f - t * t); }
                 if (MODE == 2) { a1[k] += gg; a2[k] += gg * xh; }
                 else v[k] = gm[k] * rs[k] * (gg - m1[k] - xh * m2[k]);
             }
@@ -434,7 +442,8 @@ static int bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks) {
     if (dtype == FS2_F32) bn_rows_kernel<float, MODE, NT><<<grid, NT, 0, stream>>>(a); \
     else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE, NT><<<grid, NT, 0, stream>>>(a); \
     else { fs2_set_error("bn: dtype"); return FS2_EDTYPE; } } while (0)
-#define BN_REDUCE_BLOCKS 96
+#define BN_REDUCE_BLOCKS 96        /* statistics: pure streaming, atomics-bound */
+#define BN_BWD1_BLOCKS 256         /* backward sums: tanh + dropout hash per element -> needs every CU */
 
 // stats[0..C) = sum, stats[C..2C) = sum of squared deviations  (caller zeroes stats first)
 extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype, hipStream_t stream) {
@@ -505,7 +514,7 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     BnArgs a = {};
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
-    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS);
+    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS);
     BN_LAUNCH(2, 1024, grid);
     grid = bn_geometry(a, M, C, 256, 2048);
     BN_LAUNCH(3, 256, grid);

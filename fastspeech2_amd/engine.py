@@ -209,7 +209,12 @@ class Engine:
             self._side = None
             return
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+            # lowest priority the runtime offers: when both streams have workgroups ready, the dispatcher should take the
+            # critical chain's (FS2_SIDE_PRIO overrides; torch: larger number = lower priority)
+            import os
+            lo, hi = torch.cuda.Stream.priority_range()
+            prio = int(os.environ.get("FS2_SIDE_PRIO", max(lo, hi)))
+            self._side_stream = torch.cuda.Stream(device=self.device, priority=prio)
         self._side = self._side_stream
 
     def _side_join(self):
