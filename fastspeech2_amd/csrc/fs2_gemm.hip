@@ -91,7 +91,7 @@ __device__ __forceinline__ uint4 act_chunk_bf16(uint4 v, float slope) {
 
 // final stage of the epilogue (shared by both GEMM kernels): the f32 tile staged in LDS is written out in whole
 // 16-byte row segments; residual / ReLU-gate operand and the accumulate operand are read the same way.
-template <typename T, int TW = 128, int NT = 256>
+template <typename T, int TW = 128, int NT = 256, int ROWS = 128>
 __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const float* tile, int m0, int n0, int tid) {
     constexpr int EPC = MmaTraits<T>::EPC;
     T* Y = reinterpret_cast<T*>(a.Y);
@@ -100,7 +100,7 @@ __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const flo
     constexpr int CPR = TW / EPT;            // 16-byte chunks per tile row ([128][TW] f32 tile, NT threads)
     const bool gate = a.act == FS2_ACT_GATE;
 #pragma unroll 4
-    for (int it = 0; it < (128 * CPR) / NT; ++it) {
+    for (int it = 0; it < (ROWS * CPR) / NT; ++it) {
         int idx = tid + NT * it;
         int rl = idx / CPR, cc = (idx % CPR) * EPT;
         int m = m0 + rl, n = n0 + cc;
@@ -336,17 +336,23 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(ConvGemmArgs a) {
 // [0, M) / columns outside Cin / N are fetched from a zero line.
 __device__ __attribute__((aligned(128))) unsigned int fs2_zero_line[32];
 
-template <typename T>
-__global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
+// KS = 2: in-workgroup split-K.  512 threads = two 4-wave groups that walk the even / odd Cin chunks of the SAME 128x128
+// tile through their own operand buffers (2 waves per SIMD) and add their accumulators through LDS before the epilogue.
+// For long reductions with few output tiles - the encoder's k=9 data gradient is 96 tiles x 144 K-steps on 256 CUs,
+// 185 us at one 4-wave workgroup per tile - this halves the time a tile occupies its CU.
+template <typename T, int KS>
+__global__ void __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) conv_gemm_dma_kernel(ConvGemmArgs a) {
     constexpr int EPC = MmaTraits<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int A_ROWS = 160;                                  // 128 + halo (<= 16), rounded to 20 wave-loads
     constexpr int A_BYTES = A_ROWS * 128, B_BYTES = 128 * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [A0 | A1 | B0 | B1]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];   // per group: [A0 | A1 | B0 | B1]
     typedef __attribute__((address_space(3))) void* lptr;
     typedef __attribute__((address_space(1))) const void* gptr;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;       // thread / wave index inside the 4-wave group
+    const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    unsigned char* smem = smem_all + grp * (2 * A_BYTES + 2 * B_BYTES);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntm = (a.M + 127) >> 7;
@@ -362,7 +368,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
         int b0 = m0 / a.S, b1 = mlast / a.S;
         if (b0 == b1 && (m0 - b0 * a.S) >= a.lens[b0]) {
             if (!a.accumulate) {
-                for (int i = tid; i < 128 * 128; i += 256) {
+                for (int i = threadIdx.x; i < 128 * 128; i += 256 * KS) {
                     int r = i >> 7, c = i & 127;
                     int m = m0 + r, n = n0 + c;
                     if (m < a.M && n < a.N) Elem<T>::st(Y + (size_t)m * a.ldy + n, 0.f);
@@ -371,7 +377,8 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
             return;
         }
     }
-    const int nkc = (a.Cin + BK - 1) / BK;
+    const int nkc_all = (a.Cin + BK - 1) / BK;
+    const int nkc = nkc_all / KS;                            // chunks of this group (host guarantees divisibility): kc_g = kc * KS + grp
     const int nsteps = a.taps * nkc;
     const T* zline = reinterpret_cast<const T*>(fs2_zero_line);
     // DMA lane geometry: a wave-load covers 8 rows x 128 B; lane -> (row lr, linear chunk lc), source chunk lc ^ f(row)
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
             if (wl * 8 >= 128 + (a.taps - 1) * a.dil) continue;   // wave-uniform: rows beyond the needed halo
             int r = wl * 8 + lr;                     // halo-tile row
             int g = m0 - a.pad + r;                  // global activation row
-            int col = kc * BK + ((lc ^ ((r >> 1) & 7)) * EPC);
+            int col = (kc * KS + grp) * BK + ((lc ^ ((r >> 1) & 7)) * EPC);
             const T* src = (g >= 0 && g < a.M && col < a.Cin) ? X + ((size_t)g * a.ldx + col) : zline;
             __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(dst + wl * 1024), 16, 0, 0);
         }
@@ -398,7 +405,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
             int wl = wave * 4 + j;
             int r = wl * 8 + lr;
             int n = n0 + r;
-            int col = kc * BK + ((lc ^ ((r >> 1) & 7)) * EPC);
+            int col = (kc * KS + grp) * BK + ((lc ^ ((r >> 1) & 7)) * EPC);
             const T* src = (n < a.N && col < a.Cin) ? W + ((size_t)n * a.ldw + (size_t)tap * a.Cin + col) : zline;
             __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(dst + wl * 1024), 16, 0, 0);
         }
@@ -480,7 +487,29 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
         __syncthreads();
     }
 
-    float* tile = reinterpret_cast<float*>(smem);
+    if (KS == 2) {                                         // group 1 hands its partial tile to group 0 through LDS
+        __syncthreads();                                   // (every wave has left the K loop: operand buffers are dead)
+        float* part = reinterpret_cast<float*>(smem_all);
+        if (grp == 1) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[((mb * 2 + nb) * 16 + r) * 256 + tid] = acc[mb][nb][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] += part[((mb * 2 + nb) * 16 + r) * 256 + tid];
+        }
+        __syncthreads();
+    }
+    float* tile = reinterpret_cast<float*>(smem_all);
     auto stage = [&](auto actc) {
         constexpr int ACT = decltype(actc)::value;
 #pragma unroll
@@ -497,9 +526,9 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_dma_kernel(ConvGemmArgs a) {
                 }
         }
     };
-    FS2_ACT_DISPATCH(a.act, stage(std::integral_constant<int, ACT>{}));
+    if (grp == 0) FS2_ACT_DISPATCH(a.act, stage(std::integral_constant<int, ACT>{}));
     __syncthreads();
-    gemm_store_tile<T>(a, tile, m0, n0, tid);
+    gemm_store_tile<T, 128, 256 * KS>(a, tile, m0, n0, threadIdx.x);
 }
 
 
@@ -850,6 +879,9 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     bool big = ring_ok && big_tiles >= 170 && (taps > 1 || Cin >= 1024);
     if (force_tile == 128) big = false;
     if (force_tile == 256 && ring_ok) big = true;
+    // (r01i: a weight-stationary streaming kernel for the K = 256 one-tap contractions - W block resident in LDS, X tiles
+    // prefetched a tile ahead - measured within +-5 % of the 128^2 kernel: these launches are 20-60 us and already move
+    // 1.7-3.2 TB/s; what they lose is launch ramp and tail, not pipeline bubbles.  Removed again.)
     if (big) {
         static bool ring_attr_set = false;
         const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
@@ -865,12 +897,18 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
         const int dyn = 2 * 160 * 128 + 2 * 128 * 128;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-            (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn);
             attr_set = true;
         }
-        if (dtype == FS2_F32) conv_gemm_dma_kernel<float><<<(unsigned)grid, 256, dyn, stream>>>(a);
-        else conv_gemm_dma_kernel<bf16_t><<<(unsigned)grid, 256, dyn, stream>>>(a);
+        // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
+        static const int ksplit_on = [] { const char* e = getenv("FS2_GEMM_KSPLIT"); return e ? atoi(e) : 1; }();
+        const int nkc64 = Cin / 64;
+        const bool ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * nkc64 >= 32;
+        if (dtype == FS2_F32) conv_gemm_dma_kernel<float, 1><<<(unsigned)grid, 256, dyn, stream>>>(a);
+        else if (ks2) conv_gemm_dma_kernel<bf16_t, 2><<<(unsigned)grid, 512, 2 * dyn, stream>>>(a);
+        else conv_gemm_dma_kernel<bf16_t, 1><<<(unsigned)grid, 256, dyn, stream>>>(a);
     } else if (dtype == FS2_F32) conv_gemm_kernel<float><<<(unsigned)grid, 256, 0, stream>>>(a);
     else conv_gemm_kernel<bf16_t><<<(unsigned)grid, 256, 0, stream>>>(a);
     FS2_CHECK_LAUNCH("conv_gemm");
