@@ -4,7 +4,13 @@
 // launch sequence is capturable in a hipGraph and replayable with no host-side argument changes.
 #include "fs2_common.h"
 
-__global__ void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+// ||x||^2 in two stages with a FIXED summation order: per-block partials into the caller's workspace, then one block adds
+// them in index order.  (The first version accumulated block sums with atomicAdd: the arrival order - and therefore the
+// last bits of the norm, the clip coefficient and every parameter after the Adam step - differed from run to run and,
+// in data-parallel training, from rank to rank although the all-reduced gradients were bit-identical: the two-rank test
+// tests/test_ddp_gpu.py caught replicas drifting apart by 1 ulp per step.)
+#define FS2_SUMSQ_BLOCKS 1024
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ ws) {
     __shared__ float s[4];
     float acc = 0.f;
     size_t n4 = n / 4;
@@ -16,17 +22,27 @@ __global__ void sumsq_kernel(const float* __restrict__ x, size_t n, float* __res
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
+    if (threadIdx.x == 0) ws[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
-// out[0] += sum x^2   (caller zeroes out)
-extern "C" int fs2_sumsq(const float* x, size_t n, float* out, hipStream_t stream) {
-    FS2_CHECK_ARG(x && out, "sumsq: null pointer");
+__global__ void __launch_bounds__(256) sumsq_final_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ out) {
+    __shared__ float s[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += ws[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (s[0] + s[1]) + (s[2] + s[3]);
+}
+// out[0] += sum x^2   (caller zeroes out; ws = FS2_SUMSQ_BLOCKS floats of workspace)
+extern "C" int fs2_sumsq(const float* x, size_t n, float* out, float* ws, hipStream_t stream) {
+    FS2_CHECK_ARG(x && out && ws, "sumsq: null pointer");
     FS2_CHECK_ARG(((uintptr_t)x & 15) == 0, "sumsq: x must be 16-byte aligned");
     if (n == 0) return FS2_OK;
     size_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > FS2_SUMSQ_BLOCKS) blocks = FS2_SUMSQ_BLOCKS;
     if (blocks == 0) blocks = 1;
-    sumsq_kernel<<<(unsigned)blocks, 256, 0, stream>>>(x, n, out);
+    sumsq_partial_kernel<<<(unsigned)blocks, 256, 0, stream>>>(x, n, ws);
+    sumsq_final_kernel<<<1, 256, 0, stream>>>(ws, (int)blocks, out);
     FS2_CHECK_LAUNCH("sumsq");
     return FS2_OK;
 }

@@ -421,6 +421,7 @@ class ScheduledOptim:
             self._v = torch.zeros_like(flat)
             self._hyper = torch.zeros(4, device=flat.device, dtype=torch.float32)
             self._nsq = torch.zeros(1, device=flat.device, dtype=torch.float32)
+            self._nsq_ws = torch.empty(1024, device=flat.device, dtype=torch.float32)
             if self._pending_state is not None:
                 self._load_now(self._pending_state)
                 self._pending_state = None
@@ -442,7 +443,7 @@ class ScheduledOptim:
         b1, b2 = self.betas
         g = self.model.flat_gradients()
         self._nsq.zero_()
-        ops.sumsq(g, self._nsq)
+        ops.sumsq(g, self._nsq, self._nsq_ws)
         lowp = self.model._engine.lowp_buffer() if self.model._engine is not None else None
         ops.adam_step(self.model.flat_parameters(), g, self._m, self._v, self._nsq, self.grad_clip_thresh, self._hyper,
                       b1, b2, self.eps, self.weight_decay, p_lowp=lowp, zero_grad=zero_grad)

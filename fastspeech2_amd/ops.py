@@ -288,8 +288,11 @@ def cast(x, dtype, out=None):
 
 
 # ------------------------------------------------------------------ optimiser
-def sumsq(x, out):
-    _lib.call("fs2_sumsq", _p(x), x.numel(), _p(out), _stream())
+def sumsq(x, out, ws=None):
+    """out[0] += ||x||^2, bit-reproducible (fixed summation order).  ws: >= 1024 floats of workspace."""
+    if ws is None:
+        ws = torch.empty(1024, device=x.device, dtype=torch.float32)
+    _lib.call("fs2_sumsq", _p(x), x.numel(), _p(out), _p(ws), _stream())
 
 
 def adam_step(p, g, m, v, gnorm_sq, max_norm, hyper, b1, b2, eps, wd, p_lowp=None, zero_grad=False):

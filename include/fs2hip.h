@@ -179,7 +179,9 @@ int fs2_loss_bwd(const float* mel, const float* post, const float* mel_t, long l
                  float* dp, float* de, float* dlogd, fs2_stream_t stream);
 
 /* ---- optimiser: train.py:93 clip_grad_norm_ + model/optimizer.py:10-51 Adam ------------------------- */
-int fs2_sumsq(const float* x, size_t n, float* out /*+=*/, fs2_stream_t stream);
+/* ws: FS2_SUMSQ_BLOCKS floats of workspace (two-stage reduction in a fixed order: bit-reproducible norm) */
+#define FS2_SUMSQ_BLOCKS 1024
+int fs2_sumsq(const float* x, size_t n, float* out /*+=*/, float* ws, fs2_stream_t stream);
 /* hyper (device) = {lr, 1-beta1^t, 1-beta2^t}; clip = min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)).
  * p_lowp (optional, bf16): compute-dtype copy of the updated parameters written in the same pass;
  * zero_grad: clear g as it is consumed (optimizer.zero_grad(), model/optimizer.py:30-31).  n % 4 == 0. */
