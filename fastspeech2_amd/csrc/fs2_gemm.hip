@@ -1154,44 +1154,40 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
     const unsigned char* dYb = reinterpret_cast<const unsigned char*>(dY);
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X);
     const unsigned dy_rs = (unsigned)a.lddy * 2u, x_rs = (unsigned)a.ldx * 2u;      // row strides in bytes
-    const bool small = (double)a.M * (double)dy_rs < 4.0e9 && (double)a.M * (double)x_rs < 4.0e9;   // 32-bit byte offsets
     unsigned okmask_t[2] = {0, 0};                       // edge tiles: bit i: ra[i] valid, bit 4+i: rb[i] valid, bit 8: rb4
     bool edge_t[2] = {false, false};
+    // ONE straight-line load sequence per K-tile, issued unconditionally (a tile index past the end re-reads the first
+    // tile and is marked dead).  With the loads inside `if (more)` / `if (interior) ... else ...` blocks, hipcc's waitcnt
+    // insertion put an s_waitcnt vmcnt(0) at the control-flow merge in front of the MFMA block (r01i ISA) - the prefetch
+    // was waited for immediately and every K-tile paid the full L2/HBM round trip (2 us per tile at any split depth).
     auto load_tile = [&](auto setc, int u) {
         constexpr int SET = decltype(setc)::value;
-        int seq = u / tps, t0 = (u - seq * tps) * 64;
+        const bool valid = u < uend;
+        const int uu = valid ? u : ubeg;
+        const int seq = uu / tps, t0 = (uu - seq * tps) * 64;
         const int tend = a.lens ? min(a.lens[seq], a.S) : a.S;      // rows >= tend carry zero gradient
-        live_t[SET] = t0 < tend;
-        if (!live_t[SET]) return;                          // block-uniform: a dead K-tile is neither fetched nor multiplied
-        const int row0 = seq * a.S + t0;                 // < M: fits 32 bits
-        edge_t[SET] = !col_full || !small || (t0 + 64 > tend) || (t0 + shift0 < 0) || (t0 + shift0 + XROWS > a.S);
-        if (!edge_t[SET]) {
-            const unsigned o = (unsigned)(row0 + sr) * dy_rs + (unsigned)ncol * 2u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[SET][i] = *reinterpret_cast<const uint4*>(dYb + (o + (unsigned)(16 * i) * dy_rs));
-            const unsigned ox = (unsigned)(row0 + shift0 + sr) * x_rs + (unsigned)ccol * 2u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rb[SET][i] = *reinterpret_cast<const uint4*>(Xb + (ox + (unsigned)(16 * i) * x_rs));
-            if (x5) rb4[SET] = *reinterpret_cast<const uint4*>(Xb + (ox + 64u * x_rs));
-            return;
-        }
-        size_t base = (size_t)seq * a.S;
+        live_t[SET] = valid && t0 < tend;                            // a dead K-tile is fetched (cheaply, once) but never multiplied
+        edge_t[SET] = !col_full || (t0 + 64 > tend) || (t0 + shift0 < 0) || (t0 + shift0 + XROWS > a.S);
+        const unsigned base = (unsigned)(seq * a.S);                 // rows < M: 32-bit
         unsigned ok = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int t = t0 + sr + 16 * i;
-            ra[SET][i] = *reinterpret_cast<const uint4*>(dY + (base + min(t, a.S - 1)) * a.lddy + ncol);
+            const int t = t0 + sr + 16 * i;
+            const size_t o = (size_t)(base + (unsigned)min(t, a.S - 1)) * dy_rs + (unsigned)ncol * 2u;
+            ra[SET][i] = *reinterpret_cast<const uint4*>(dYb + o);
             ok |= (ncol_ok && t < tend) ? (1u << i) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int t = t0 + shift0 + sr + 16 * i;
-            rb[SET][i] = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
+            const int t = t0 + shift0 + sr + 16 * i;
+            const size_t o = (size_t)(base + (unsigned)min(max(t, 0), a.S - 1)) * x_rs + (unsigned)ccol * 2u;
+            rb[SET][i] = *reinterpret_cast<const uint4*>(Xb + o);
             ok |= (ccol_ok && t >= 0 && t < a.S) ? (16u << i) : 0u;
         }
-        if (x5) {                                        // wave-uniform
-            int t = t0 + shift0 + sr + 64;
-            rb4[SET] = *reinterpret_cast<const uint4*>(X + (base + min(max(t, 0), a.S - 1)) * a.ldx + ccol);
+        {
+            const int t = t0 + shift0 + sr + 64;                     // halo rows 64..71: needed from the first 128 threads only,
+            const size_t o = (size_t)(base + (unsigned)min(max(t, 0), a.S - 1)) * x_rs + (unsigned)ccol * 2u;
+            rb4[SET] = *reinterpret_cast<const uint4*>(Xb + o);      // loaded by everyone to keep the sequence branch-free
             ok |= (ccol_ok && t >= 0 && t < a.S) ? 256u : 0u;
         }
         okmask_t[SET] = ok;
@@ -1287,7 +1283,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
     // tile u lives in LDS buffer (u - ubeg) & 1 while it is multiplied; tile u+1 waits in register stage ((u+1-ubeg) & 1),
     // tile u+2 is being fetched into stage ((u-ubeg) & 1) (whose previous content, tile u, went to LDS one step earlier).
     load_tile(I0{}, ubeg);
-    if (ubeg + 1 < uend) load_tile(I1{}, ubeg + 1);
+    load_tile(I1{}, ubeg + 1);
     bool live_lds[2] = {live_t[0], false};
     if (live_t[0]) store_tile(I0{}, 0);
     __syncthreads();
@@ -1297,7 +1293,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
         constexpr int bufoff = BUF * (A_BYTES + X_BYTES);
         const bool live = live_lds[BUF] && !(a.dbg & 2);
         if (live) read_frags(0, bufoff, 0);
-        if (u + 2 < uend) load_tile(std::integral_constant<int, BUF>{}, u + 2); else live_t[BUF] = false;
+        load_tile(std::integral_constant<int, BUF>{}, u + 2);
         if (live) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {

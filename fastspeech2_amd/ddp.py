@@ -27,7 +27,9 @@ class GradExchange:
         self.n = flat_grad.numel()
         self.cuda = flat_grad.is_cuda
         self.overlap = overlap and self.cuda
-        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        # high priority: the collective's few workgroups must get CUs while backward still fills the device, otherwise the
+        # exchange only starts moving once compute drains and nothing overlaps
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device, priority=-1) if self.cuda else None
         self.reset()
 
     def reset(self):
