@@ -546,24 +546,31 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (k0 + kb * 32 >= len) break;
+            // software pipeline over the 8 d-slices (K and V fragments of slice st+1 in flight while slice st is multiplied);
+            // sched_barrier pins it (hoisting the 8 transposed K fragments too spills at 2 waves per SIMD)
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            {
+                bf16x8 ck = frag_k(sK, kb * 32 + fl, 0, h2), cv = frag_k(sV, kb * 32 + fl, 0, h2);
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sK, kb * 32 + fl, st, h2), qf[st], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_k(sV, kb * 32 + fl, st, h2), df[st], dp, 0, 0, 0);
+                for (int st = 0; st < 8; ++st) {
+                    bf16x8 nk = ck, nv = cv;
+                    if (st < 7) { nk = frag_k(sK, kb * 32 + fl, st + 1, h2); nv = frag_k(sV, kb * 32 + fl, st + 1, h2); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ck, qf[st], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cv, df[st], dp, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ck = nk; cv = nv;
+                }
             }
             float dsv[16];
+            const float qok = q_ok ? 1.f : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int key = k0 + kb * 32 + crow(r, h2);
-                float ds = 0.f;
-                if (q_ok && key < len) {
-                    float p = __expf(s[r] * scale - my_lse);
-                    ds = p * (dp[r] - my_del) * scale;
-                }
-                dsv[r] = ds;
+                const int key = k0 + kb * 32 + crow(r, h2);
+                const float p = __expf(s[r] * scale - my_lse) * (key < len ? qok : 0.f);
+                dsv[r] = p * (dp[r] - my_del) * scale;
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
