@@ -48,9 +48,11 @@ class Engine:
         self.grad_hook = None   # callable(end_offset): flat_grad[0:end_offset) is final (see ddp.GradExchange.ready)
         import os
         self.use_side_stream = os.environ.get("FS2_SIDE_STREAM", "1") != "0"
+        self._skip_wgrad = os.environ.get("FS2_SKIP_WGRAD", "0") == "1"
         self._side_stream = None
         self._side = None
         self._side_keep = []
+        self._pack_pending = False
 
     # ------------------------------------------------------------------ weights
     def _flat_view(self, first_name, numel, shape, grad=False):
@@ -140,7 +142,17 @@ class Engine:
                 ops.cast(self.m._flat, self.cdt, out=self._flat_lp)
                 self.lp_synced = True
             if need_dgrad:
-                ops.pack_dgrad_multi(self.m._flat, self._wd_all, self._pack_table, self._pack_tiles)
+                # the data-gradient packs are first read in BACKWARD: pack them on the side stream, off the forward chain
+                if self.use_side_stream:
+                    if self._side_stream is None:
+                        self._side_stream = torch.cuda.Stream(device=self.device)
+                    cur = torch.cuda.current_stream()
+                    self._side_stream.wait_stream(cur)
+                    with ops.pinned_stream(self._side_stream):
+                        ops.pack_dgrad_multi(self.m._flat, self._wd_all, self._pack_table, self._pack_tiles)
+                    self._pack_pending = True
+                else:
+                    ops.pack_dgrad_multi(self.m._flat, self._wd_all, self._pack_table, self._pack_tiles)
             self._packed_has_dgrad = need_dgrad
             self.weights_dirty = False
         return self._packed
@@ -190,6 +202,8 @@ class Engine:
         downstream reads them until the optimiser), so they are issued on a side HIP stream: they fill the CUs that the
         data-gradient chain's kernels leave idle in their last partial round of workgroups (e.g. the k=9 data gradient runs
         348 one-per-CU workgroups = 1.36 rounds) and overlap the chain's small latency-bound launches."""
+        if self._skip_wgrad:                    # dev ablation (FS2_SKIP_WGRAD=1): how long is the critical chain alone?
+            return
         if gw.dim() == 3:
             gw = gw.permute(0, 2, 1)            # tap-major storage of the gradient
         side = self._side
@@ -205,16 +219,14 @@ class Engine:
         """fork: weight gradients of this backward go to the side stream (FS2_SIDE_STREAM=0 keeps one stream)."""
         self._side_keep = []
         self._main = torch.cuda.current_stream()
+        if self._pack_pending:                  # data-gradient packs were written on the side stream during forward
+            self._main.wait_stream(self._side_stream)
+            self._pack_pending = False
         if not self.use_side_stream:
             self._side = None
             return
         if self._side_stream is None:
-            # lowest priority the runtime offers: when both streams have workgroups ready, the dispatcher should take the
-            # critical chain's (FS2_SIDE_PRIO overrides; torch: larger number = lower priority)
-            import os
-            lo, hi = torch.cuda.Stream.priority_range()
-            prio = int(os.environ.get("FS2_SIDE_PRIO", max(lo, hi)))
-            self._side_stream = torch.cuda.Stream(device=self.device, priority=prio)
+            self._side_stream = torch.cuda.Stream(device=self.device)      # normal priority; the step runs on a high one
         self._side = self._side_stream
 
     def _side_join(self):

@@ -51,3 +51,23 @@ if len(sys.argv) > 3:
         print(f"\n## timeline\n\nspan {span/1e6:.3f} ms, some kernel running {busy/1e6:.3f} ms ({100*busy/span:.1f} %), idle {(span-busy)/1e6:.3f} ms in {len(gaps)} gaps "
               f"(gaps > 20 us: {sum(1 for g in gaps if g > 20000)}, their sum {sum(g for g in gaps if g > 20000)/1e6:.3f} ms; "
               f"gaps 2-20 us: {sum(1 for g in gaps if 2000 < g <= 20000)}, sum {sum(g for g in gaps if 2000 < g <= 20000)/1e6:.3f} ms)")
+
+# ---- steady state only: between the end of the 3rd and of the last adam_kernel launch (whole train steps, no start-up)
+if len(sys.argv) > 3:
+    ad = c.execute(f"select end from kernels where {name_col} like '%adam_kernel%' order by end").fetchall()
+    if len(ad) >= 5:
+        w0, w1 = ad[2][0], ad[-1][0]
+        nst = len(ad) - 3
+        iv = c.execute("select start, end from kernels where end > ? and start < ? order by start", (w0, w1)).fetchall()
+        busy, cur_s, cur_e, ngap, gsum = 0, max(iv[0][0], w0), iv[0][1], 0, 0
+        for s0, e0 in iv[1:]:
+            s0 = max(s0, w0); e0 = min(e0, w1)
+            if s0 > cur_e:
+                busy += cur_e - cur_s; ngap += 1; gsum += s0 - cur_e
+                cur_s, cur_e = s0, e0
+            else:
+                cur_e = max(cur_e, e0)
+        busy += cur_e - cur_s
+        ksum = c.execute("select sum(end-start) from kernels where start >= ? and end <= ?", (w0, w1)).fetchone()[0]
+        print(f"\n## steady state ({nst} steps)\n\n{(w1-w0)/1e6/nst:.3f} ms/step wall; device busy {busy/1e6/nst:.3f} ms/step, idle {gsum/1e6/nst:.3f} ms/step in {ngap/nst:.0f} gaps; "
+              f"sum of kernel durations {ksum/1e6/nst:.3f} ms/step (overlap factor {ksum/busy:.2f})")
