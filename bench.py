@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--graph", type=int, default=0,
                     help="1: replay the train step from a hipGraph.  Default 0 (eager): weight gradients run on a side HIP stream "
                          "concurrently with the data-gradient chain, which the graph executor serialises (r01i A/B: 12.8 vs 14.2 ms)")
+    ap.add_argument("--workload", default="ljspeech", choices=["ljspeech", "libritts"],
+                    help="ljspeech: BASELINE configs[1] (the reported metric).  libritts: configs[3]'s shape per GPU - multi-speaker "
+                         "(2456-way speaker embedding), LibriTTS-like phoneme counts (median ~49, p95 ~176), length-bucketed batch")
     ap.add_argument("--main-prio", type=int, default=-1,
                     help="priority of the stream the step runs on (-1 = high: the dispatcher prefers the critical fwd/dgrad chain over "
                          "the side stream's weight gradients; 0 = run on the default stream)")
@@ -59,12 +62,29 @@ def build(args, device, rank, world):
     from fastspeech2_amd.model import FastSpeech2, FastSpeech2Loss, ScheduledOptim
     from fastspeech2_amd import ddp
 
-    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
+    libri = args.workload == "libritts"
+    if libri:
+        import json as _json, tempfile
+        d = tempfile.mkdtemp(prefix="fs2_libritts_")
+        _json.dump({f"spk{i}": i for i in range(2456)}, open(os.path.join(d, "speakers.json"), "w"))
+        _json.dump(configs.LJ_STATS, open(os.path.join(d, "stats.json"), "w"))
+    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4, multi_speaker=libri)
+    if libri:
+        pcfg["path"]["preprocessed_path"] = d
     torch.manual_seed(1234)
     model = FastSpeech2(pcfg, mcfg, compute_dtype=args.dtype).to(device)
     model.train()
     model._ensure_flat(device)
-    b = synthetic_batch(1234 + rank, args.batch, args.phonemes, dur_lo=4, dur_hi=10, min_len_frac=0.75)
+    if libri:
+        # one length-bucketed batch out of a LibriTTS-like pool: log-normal phoneme counts (median 49, p95 ~176), the
+        # pool is sorted and this rank takes the bucket at the 75th percentile (what BucketedBatchSampler deals per step)
+        g = torch.Generator().manual_seed(99)
+        pool = torch.clamp(torch.exp(torch.randn(4096, generator=g) * 0.78 + 3.89), 5, 250).long()
+        pool, _ = torch.sort(pool, descending=True)
+        L = int(pool[1024])
+        b = synthetic_batch(1234 + rank, args.batch, L, dur_lo=4, dur_hi=10, min_len_frac=float(pool[1024 + args.batch]) / L, n_speaker=2456)
+    else:
+        b = synthetic_batch(1234 + rank, args.batch, args.phonemes, dur_lo=4, dur_hi=10, min_len_frac=0.75)
     b = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     loss_fn = FastSpeech2Loss(pcfg, mcfg, count_reduce=ddp.global_counts if world > 1 else None)
     opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
@@ -347,8 +367,10 @@ def main():
             "metric": "mel-frames/sec (train, 80-bin)", "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: LJSpeech train, 4+4 FFT layers d=256 2 heads, 80-bin mel, "
-                                   f"batch={args.batch}/GPU, L={args.phonemes} phonemes, T={b['max_mel_len']} frames, "
+            "config": {"workload": ("BASELINE configs[3] shape per GPU: LibriTTS-like multi-speaker (2456 speakers) bucketed batch, "
+                                    if args.workload == "libritts" else "BASELINE configs[1]: LJSpeech train, ") +
+                                   "4+4 FFT layers d=256 2 heads, 80-bin mel, "
+                                   f"batch={args.batch}/GPU, L={b['max_src_len']} phonemes, T={b['max_mel_len']} frames, "
                                    "fwd+loss+bwd+clip+Adam, dropout on, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),

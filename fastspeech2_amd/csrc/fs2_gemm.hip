@@ -847,6 +847,146 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
     gemm_store_tile<bf16_t, 128, 512>(a, tile + 128 * 128, m0 + 128, n0, tid);
 }
 
+// =====================================================================================================
+// "Skinny" convolution: Cin == Cout == C in {32, 64, 128}, bf16 - the HiFi-GAN residual blocks after the first
+// upsampling stage (hifigan/models.py:96-103): M = B * T * up is huge (1.8 M rows per 8 utterances at the last stage),
+// C is tiny.  These layers are HBM-bound by construction (C=32, k=3: 48 FLOP per byte; every conv moves M*C*2 bytes in
+// and out = 236 MB at every stage), and the general kernels waste them: a 128x128 tile computes 4x / 2x more columns
+// than exist, the K-chunk of 64 is half padding at C=32, and the A tile is re-staged per tap (r01j trace: 470 us per
+// C=32 conv = 0.5 TB/s, 39 % of the whole synthesis step).
+// Here one workgroup owns 128 rows x all C columns: the activation tile is staged ONCE with its full dilation halo
+// (leaky-ReLU applied while staging), the weights of a group of taps sit in LDS next to it, each wave multiplies
+// 32 rows x C columns tap by tap from those two tiles, and the shared epilogue (bias, activation, residual,
+// accumulate, 1/3 scale) writes whole rows.  X is read once, Y written once: ~24 KB of HBM traffic per 128 rows.
+// LDS rows are C*2 bytes; 16-byte chunk c of row r is stored at chunk c ^ ((r / RPW) % CPR) (CPR = chunks per row,
+// RPW = rows per 256-byte bank window), which makes the ds_read_b128 of one chunk by 16 consecutive rows conflict-free
+// for all three widths.
+template <int C> struct SkinnyCfg {
+    static constexpr int CPR = C / 8, RPW = 16 / CPR, XR_MAX = 192;
+    static constexpr int G = C == 32 ? 8 : (C == 64 ? 2 : 1);          // taps per weight group (16 / 16 / 32 KB)
+    static constexpr int X_BYTES = XR_MAX * C * 2, W_BYTES = G * C * C * 2;
+    static constexpr int EPI_BYTES = 128 * C * 4;
+    static constexpr int LDS = (X_BYTES + W_BYTES) > EPI_BYTES ? (X_BYTES + W_BYTES) : EPI_BYTES;
+};
+template <int C> __device__ __forceinline__ unsigned skinny_swz(int row, int c) {
+    typedef SkinnyCfg<C> K;
+    return (unsigned)(row * (C * 2) + ((c ^ ((row / K::RPW) % K::CPR)) << 4));
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) conv_skinny_kernel(ConvGemmArgs a) {
+    typedef SkinnyCfg<C> K;
+    constexpr int CPR = K::CPR, NB = C / 32, NS = C / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sW = smem + K::X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, fl = lane & 31, fh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 128;
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+    const int halo = (a.taps - 1) * a.dil;
+    const int xr = 128 + halo;                              // staged rows: global rows m0 - pad .. m0 - pad + xr - 1
+    // ---- stage X (all loads first, then activation + swizzled stores)
+    constexpr int MAXI = (K::XR_MAX * CPR + 255) / 256;
+    uint4 xv[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / CPR, c = idx % CPR;
+        const int g = m0 - a.pad + row;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < xr && g >= 0 && g < a.M) v = *reinterpret_cast<const uint4*>(X + (size_t)g * a.ldx + c * 8);
+        xv[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / CPR, c = idx % CPR;
+        if (row < xr) {
+            uint4 v = xv[i];
+            if (a.in_act == FS2_ACT_LRELU) v = act_chunk_bf16(v, a.in_slope);
+            *reinterpret_cast<uint4*>(sX + skinny_swz<C>(row, c)) = v;
+        }
+    }
+    // tap-validity bitmask of this lane's output row (bit j: tap j stays inside the row's own sequence)
+    unsigned vmask = 0;
+    {
+        const int m = m0 + wave * 32 + fl;
+        if (m < a.M) {
+            const int t = m % a.S;
+            for (int j = 0; j < a.taps; ++j) {
+                const int ts = t + j * a.dil - a.pad;
+                if (ts >= 0 && ts < a.S) vmask |= 1u << j;
+            }
+        }
+    }
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    constexpr int WI = (K::G * C * CPR) / 256;              // 16-byte chunks of a weight group per thread (4 / 4 / 8)
+    for (int g0 = 0; g0 < a.taps; g0 += K::G) {
+        __syncthreads();                                   // X tile visible / previous weight group consumed
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int idx = tid + 256 * i;
+            const int tl = idx / (C * CPR), rem = idx % (C * CPR);
+            const int n = rem / CPR, c = rem % CPR;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g0 + tl < a.taps) v = *reinterpret_cast<const uint4*>(W + ((size_t)n * a.taps + (g0 + tl)) * C + c * 8);
+            *reinterpret_cast<uint4*>(sW + tl * (C * C * 2) + skinny_swz<C>(n, c)) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < K::G; ++tl) {
+            const int tap = g0 + tl;
+            if (tap >= a.taps) break;                      // block-uniform
+            const int r = wave * 32 + fl + tap * a.dil;    // my row inside the halo tile
+            const bool live = (vmask >> tap) & 1u;
+            const unsigned char* wt = sW + tl * (C * C * 2);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const int c = 2 * sl + fh;
+                uint4 av = *reinterpret_cast<const uint4*>(sX + skinny_swz<C>(r, c));
+                if (!live) av = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    uint4 bv = *reinterpret_cast<const uint4*>(wt + skinny_swz<C>(nb * 32 + fl, c));
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                       // operand tiles dead: LDS becomes the f32 staging tile
+    float* tile = reinterpret_cast<float*>(smem);
+    auto stage = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int cl = nb * 32 + fl;
+            const float bv = a.bias ? a.bias[cl] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                tile[rl * C + cl] = act_ct<ACT>(acc[nb][r] + bv, a.slope);
+            }
+        }
+    };
+    FS2_ACT_DISPATCH(a.act, stage(std::integral_constant<int, ACT>{}));
+    __syncthreads();
+    gemm_store_tile<bf16_t, C, 256, 128>(a, tile, m0, 0, tid);
+}
+
+template <int C>
+static void launch_skinny(const ConvGemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_skinny_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, SkinnyCfg<C>::LDS); attr_set = true; }
+    conv_skinny_kernel<C><<<(unsigned)fs2_cdiv(a.M, 128), 256, SkinnyCfg<C>::LDS, stream>>>(a);
+}
+
 extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
                              long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad,
                              int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
@@ -882,7 +1022,14 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     // (r01i: a weight-stationary streaming kernel for the K = 256 one-tap contractions - W block resident in LDS, X tiles
     // prefetched a tile ahead - measured within +-5 % of the 128^2 kernel: these launches are 20-60 us and already move
     // 1.7-3.2 TB/s; what they lose is launch ramp and tail, not pipeline bubbles.  Removed again.)
-    if (big) {
+    static const int use_skinny = [] { const char* e = getenv("FS2_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+    const bool skinny = use_skinny && dtype == FS2_BF16 && N == Cin && (Cin == 32 || Cin == 64 || Cin == 128) && taps <= 16 &&
+                        (taps - 1) * dil <= 64 && (in_act == FS2_ACT_NONE || in_act == FS2_ACT_LRELU) && a.vec_ok;
+    if (skinny) {
+        if (Cin == 32) launch_skinny<32>(a, stream);
+        else if (Cin == 64) launch_skinny<64>(a, stream);
+        else launch_skinny<128>(a, stream);
+    } else if (big) {
         static bool ring_attr_set = false;
         const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
         const int dynk = RingCfg<false>::B_OFF + RingCfg<false>::D * RING_B_BYTES;
