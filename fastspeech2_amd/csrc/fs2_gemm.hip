@@ -1022,8 +1022,11 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     // (r01i: a weight-stationary streaming kernel for the K = 256 one-tap contractions - W block resident in LDS, X tiles
     // prefetched a tile ahead - measured within +-5 % of the 128^2 kernel: these launches are 20-60 us and already move
     // 1.7-3.2 TB/s; what they lose is launch ramp and tail, not pipeline bubbles.  Removed again.)
-    static const int use_skinny = [] { const char* e = getenv("FS2_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
-    const bool skinny = use_skinny && dtype == FS2_BF16 && N == Cin && (Cin == 32 || Cin == 64 || Cin == 128) && taps <= 16 &&
+    // C = 128 stays on the 256x128 / 128^2 kernels: it is MFMA-bound there (k=11: 172 GFLOP per conv) and one tap per
+    // weight group leaves only 32 MFMAs per wave between barriers (r01j A/B: 13.1 ms with, 12.0 ms without bit 4|8)
+    static const int skinny_mask = [] { const char* e = getenv("FS2_GEMM_SKINNY"); return e ? atoi(e) : 3; }();    // dev A/B bits
+    const int skinny_bit = Cin == 32 ? 1 : (Cin == 64 ? 2 : (in_act == FS2_ACT_NONE ? 4 : 8));
+    const bool skinny = (skinny_mask & skinny_bit) && dtype == FS2_BF16 && N == Cin && (Cin == 32 || Cin == 64 || Cin == 128) && taps <= 16 &&
                         (taps - 1) * dil <= 64 && (in_act == FS2_ACT_NONE || in_act == FS2_ACT_LRELU) && a.vec_ok;
     if (skinny) {
         if (Cin == 32) launch_skinny<32>(a, stream);
