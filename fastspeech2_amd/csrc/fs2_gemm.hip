@@ -861,6 +861,9 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
 // LDS rows are C*2 bytes; 16-byte chunk c of row r is stored at chunk c ^ ((r / RPW) % CPR) (CPR = chunks per row,
 // RPW = rows per 256-byte bank window), which makes the ds_read_b128 of one chunk by 16 consecutive rows conflict-free
 // for all three widths.
+// (r01j: fusing a residual block's conv1 -> leaky-ReLU -> conv2 + residual into one kernel, intermediate in LDS, was tried
+// for C = 32 / 64: 2.5x less HBM traffic on paper, but two weight-group loops with a barrier pair per group (24 barriers at
+// k = 11) and 1-2 workgroups per CU made the synthesis step 24 % SLOWER than two skinny launches.  Not kept.)
 template <int C> struct SkinnyCfg {
     static constexpr int CPR = C / 8, RPW = 16 / CPR, XR_MAX = 192;
     static constexpr int G = C == 32 ? 8 : (C == 64 ? 2 : 1);          // taps per weight group (16 / 16 / 32 KB)
