@@ -534,10 +534,13 @@ __global__ void __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) conv_gemm_dma_kerne
 
 // =====================================================================================================
 // Ring-buffered, wave-specialised variant for the large bf16 contractions.
-// 256(M) x 128(N) tile, ONE 512-thread workgroup per CU = two waves per SIMD with different jobs:
-//   waves 0-3  CONSUMERS (2(M) x 2(N), each a 128x64 sub-tile = 4x2 MFMA 32x32x16 blocks, 128 accumulator registers):
+// 256(M) x 128(N) tile, ONE 768-thread workgroup per CU = three waves per SIMD (r01j: was 512 threads = one consumer +
+// one loader wave per SIMD with 128x64 consumer tiles; a lone consumer wave cannot overlap its own ds_read bursts with
+// its MFMAs - ablation: ~1000 cycles of MFMA + ~800 cycles of fragment-read issue per K-step, serial - two 64x64 consumer
+// waves per SIMD interleave them for free):
+//   waves 0-7  CONSUMERS (4(M) x 2(N), each a 64x64 sub-tile = 2x2 MFMA 32x32x16 blocks, 64 accumulator registers):
 //              ds_read_b128 fragment loads + MFMA only;
-//   waves 4-7  LOADERS: LDS-DMA of the activation / weight tiles into rings of LDS slots, D-1 K-steps ahead.
+//   waves 8-11 LOADERS: LDS-DMA of the activation / weight tiles into rings of LDS slots, D-1 K-steps ahead.
 // What the measurements said (w_1 k=9 forward, M=43200 N=1024 K=2304; PMC + s_memtime phase timers):
 //   * 128^2 kernels: waves parked 43-63 % of their cycles in vmcnt(0)+barrier at the end of every K-step, ~14
 //     non-MFMA instructions issued per MFMA, MFMA pipe 25-29 % busy;
@@ -664,7 +667,7 @@ __device__ __forceinline__ void ring_loader(const ConvGemmArgs& a, unsigned char
 
 // ---- consumer waves (wave = 0..3 as 2 x 2): fragment reads + MFMA
 template <bool ONE_TAP, bool MASK>
-__device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned char* smem, f32x16 (&acc)[4][2], int m0, int lane,
+__device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned char* smem, f32x16 (&acc)[2][2], int m0, int lane,
                                               int wm, int wn) {
     typedef RingCfg<ONE_TAP> C;
     constexpr int D = C::D;
@@ -678,11 +681,11 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
         int r = wn * 64 + fl;
         boff[j] = r * 128 + (((fh * 4 + j) ^ ((r >> 1) & 7)) << 4);
     }
-    unsigned vmask[4] = {0, 0, 0, 0};
+    unsigned vmask[2] = {0, 0};
     if (MASK) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            int m = m0 + wm * 128 + mb * 32 + fl;
+        for (int mb = 0; mb < 2; ++mb) {
+            int m = m0 + wm * 64 + mb * 32 + fl;
             unsigned msk = 0;
             if (m < a.M) {
                 int t = m % a.S;
@@ -694,8 +697,8 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
             vmask[mb] = msk;
         }
     }
-    // Fragments are fetched in HALF-STEP groups (two 16-wide k-slices = 12 ds_read_b128, 16 MFMAs): the reads of the next
-    // group are issued before the 16 MFMAs (512 cycles) of the current one.
+    // Fragments are fetched in HALF-STEP groups (two 16-wide k-slices = 8 ds_read_b128, 8 MFMAs per wave): the reads of the
+    // next group are issued before the MFMAs of the current one.
     // The reads are issued from inline asm and waited for with a hand-counted s_waitcnt, fenced by sched_barrier(0):
     //   * left to itself the machine scheduler sinks every ds_read down to just above the MFMA that consumes it and the
     //     software prefetch is gone (r01i ISA: s_waitcnt lgkmcnt(2)/(1)/(0) right behind freshly issued reads inside the
@@ -703,15 +706,15 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
     //   * with the order pinned by sched_barrier alone, the waitcnt-insertion pass still emits lgkmcnt(0) in front of
     //     every MFMA group (the older group's reads were issued across the loop back edge / the barrier branch), which
     //     waits for the 12 reads that were JUST issued - the same serialisation.
-    // lgkmcnt counts LDS operations in order: with 12 younger reads allowed in flight, lgkmcnt(12) == "the older group
+    // lgkmcnt counts LDS operations in order: with 8 younger reads allowed in flight, lgkmcnt(8) == "the older group
     // has landed".  Nothing else in this loop touches lgkmcnt (no SMEM, no LDS stores in consumer waves).
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define FS2_DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
-    u32x4 af[2][2][4], bf[2][2][2];
+    u32x4 af[2][2][2], bf[2][2][2];
     const unsigned smem_u = lds_addr(smem);
     auto read_group = [&](int set, int kc, int tap, int slot, int g) {
         const int roff = tap * a.dil;
-        const unsigned a_base = (ONE_TAP ? slot : (kc & 1)) * C::A_BYTES + (wm * 128 + roff) * 128;
+        const unsigned a_base = (ONE_TAP ? slot : (kc & 1)) * C::A_BYTES + (wm * 64 + roff) * 128;
         const unsigned x = ((fl + roff) >> 1) & 7;         // swizzle key of the physical halo row
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -722,15 +725,13 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
             FS2_DS_READ_B128(bf[set][q][1], baddr, 4096);
             FS2_DS_READ_B128(af[set][q][0], aaddr, 0);
             FS2_DS_READ_B128(af[set][q][1], aaddr, 4096);
-            FS2_DS_READ_B128(af[set][q][2], aaddr, 8192);
-            FS2_DS_READ_B128(af[set][q][3], aaddr, 12288);
         }
     };
     auto mfma_group = [&](int set, int tap) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
+            for (int mb = 0; mb < 2; ++mb) {
                 u32x4 av = af[set][q][mb];
                 if (MASK && !((vmask[mb] >> tap) & 1u)) av = u32x4{0u, 0u, 0u, 0u};     // tap leaves the row's sequence
 #pragma unroll
@@ -746,7 +747,7 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
     for (int kc = 0; kc < nkc; ++kc) {
         for (int tap = 0; tap < taps; ++tap, ++step) {
             read_group(1, kc, tap, slot, 1);
-            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");      // first half (12 older reads) has landed
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // first half (8 older reads) has landed
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(0, tap);
             __builtin_amdgcn_sched_barrier(0);
@@ -768,11 +769,11 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
 }
 
 template <bool ONE_TAP>
-__global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) {
+__global__ void __launch_bounds__(768, 3) conv_gemm_ring_kernel(ConvGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int wm = (wave >> 1) & 3, wn = wave & 1;          // consumer wave grid 4 (M) x 2 (N), 64 x 64 each
     const int ntm = (a.M + 255) >> 8;
     const int tile_m = blockIdx.x % ntm, tile_n = blockIdx.x / ntm;
     const int m0 = tile_m * 256, n0 = tile_n * 128;
@@ -783,7 +784,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
         int b0 = m0 / a.S, b1 = mlast / a.S;
         if (b0 == b1 && (m0 - b0 * a.S) >= a.lens[b0]) {
             if (!a.accumulate) {
-                for (int i = tid; i < 256 * 16; i += 512) {              // 16-byte zero stores where the row allows it
+                for (int i = tid; i < 256 * 16; i += 768) {              // 16-byte zero stores where the row allows it
                     int r = i >> 4, c = (i & 15) * 8;
                     int m = m0 + r, n = n0 + c;
                     if (m >= a.M || n >= a.N) continue;
@@ -796,12 +797,12 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
         }
     }
     if (a.dbg & 16) return;
-    f32x16 acc[4][2];
-    if (wave >= 4) {
-        ring_loader<ONE_TAP>(a, smem, m0, n0, lane, wave - 4);
+    f32x16 acc[2][2];
+    if (wave >= 8) {
+        ring_loader<ONE_TAP>(a, smem, m0, n0, lane, wave - 8);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -821,7 +822,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
 
     // epilogue: the whole 256x128 f32 tile through LDS (128 KB), written by the consumers, stored by all 8 waves
     float* tile = reinterpret_cast<float*>(smem);
-    if (wave < 4) {
+    if (wave < 8) {
         const int fl = lane & 31, fh = lane >> 5;
         auto stage = [&](auto actc) {
             constexpr int ACT = decltype(actc)::value;
@@ -831,10 +832,10 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
                 int n = n0 + cl;
                 float bv = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        int rl = wm * 128 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        int rl = wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                         tile[rl * 128 + cl] = act_ct<ACT>(acc[mb][nb][r] + bv, a.slope);
                     }
             }
@@ -843,8 +844,10 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_ring_kernel(ConvGemmArgs a) 
     }
     __syncthreads();
     if (a.dbg & 32) { if (tile[tid] == 12345.f) Y[0] = 0; return; }
-    gemm_store_tile<bf16_t, 128, 512>(a, tile, m0, n0, tid);
-    gemm_store_tile<bf16_t, 128, 512>(a, tile + 128 * 128, m0 + 128, n0, tid);
+    if (tid < 512) {                                       // (the shared store path walks 128 x 16 chunks in whole strides of its thread count)
+        gemm_store_tile<bf16_t, 128, 512>(a, tile, m0, n0, tid);
+        gemm_store_tile<bf16_t, 128, 512>(a, tile + 128 * 128, m0 + 128, n0, tid);
+    }
 }
 
 // =====================================================================================================
@@ -1044,8 +1047,8 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
             (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
             ring_attr_set = true;
         }
-        if (taps == 1) conv_gemm_ring_kernel<true><<<(unsigned)big_tiles, 512, dyn1, stream>>>(a);
-        else conv_gemm_ring_kernel<false><<<(unsigned)big_tiles, 512, dynk, stream>>>(a);
+        if (taps == 1) conv_gemm_ring_kernel<true><<<(unsigned)big_tiles, 768, dyn1, stream>>>(a);
+        else conv_gemm_ring_kernel<false><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
     } else if (dma) {
         const int dyn = 2 * 160 * 128 + 2 * 128 * 128;
         static bool attr_set = false;
