@@ -1275,13 +1275,18 @@ __device__ __forceinline__ int wg_swz(int row, int c16) { return row * 256 + (((
 // ~6600 cycles per K-tile against 1536 cycles of MFMA work.  Now: fragments are double-buffered across the four
 // 16-row sub-steps (reads of sub-step s+1 issued before the MFMAs of s), global loads are branch-free (clamped
 // address + select) and issued before the K-tile's MFMAs, stored to the other LDS buffer after them.
-template <int NT>
+// NW = waves per workgroup: 4 (each 64 n x 64 c) or 8 (each 64 n x 32 c: two waves per SIMD - the tap-group kernels hold
+// 3 x 64 accumulators per 64x64 wave tile, which pins a 4-wave workgroup to ONE wave per SIMD with nothing to switch to
+// while a wave waits on LDS or the barrier; halving the wave tile lets two waves share a SIMD)
+template <int NT, int NW>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned char* smem, int tile_n, int tile_c, int tap0) {
     constexpr int XROWS = 64 + 8;                       // halo capacity: (NT-1)*dil <= 8
     constexpr int A_BYTES = 64 * 256, X_BYTES = XROWS * 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int NBC = NW == 4 ? 2 : 1;                  // 32-column blocks per wave
+    constexpr int RS = NW * 4, NI = 64 / RS;             // staging: rows per pass, passes per 64-row tile
+    const int wm = NW == 4 ? (wave >> 1) : (wave >> 2), wn = NW == 4 ? (wave & 1) : (wave & 3);
     const int n0 = tile_n * 128, c0 = tile_c * 128;
     const int shift0 = tap0 * a.dil - a.pad;
     const int tps = (a.S + 63) >> 6;                    // K-tiles per sequence
@@ -1298,7 +1303,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
     const bool x5 = wave < 2;                            // halo rows 64..71 are staged by the first 128 threads
     // TWO register stages (prefetch distance 2 K-tiles: a tile's loads get two tile-times - ~2-4 us - to arrive; with
     // one stage every K-tile waited out the L2/HBM round trip: 2 us per tile against 0.77 us of MFMA work, at ANY split count)
-    uint4 ra[2][4], rb[2][4], rb4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    uint4 ra[2][NI], rb[2][NI], rb4[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     bool live_t[2] = {false, false};
     const bool do_bias = a.dbias != nullptr && tile_c == 0 && tap0 == 0;     // block-uniform
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1327,15 +1332,15 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
         const unsigned base = (unsigned)(seq * a.S);                 // rows < M: 32-bit
         unsigned ok = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = t0 + sr + 16 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int t = t0 + sr + RS * i;
             const size_t o = (size_t)(base + (unsigned)min(t, a.S - 1)) * dy_rs + (unsigned)ncol * 2u;
             ra[SET][i] = *reinterpret_cast<const uint4*>(dYb + o);
             ok |= (ncol_ok && t < tend) ? (1u << i) : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = t0 + shift0 + sr + 16 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int t = t0 + shift0 + sr + RS * i;
             const size_t o = (size_t)(base + (unsigned)min(max(t, 0), a.S - 1)) * x_rs + (unsigned)ccol * 2u;
             rb[SET][i] = *reinterpret_cast<const uint4*>(Xb + o);
             ok |= (ccol_ok && t >= 0 && t < a.S) ? (16u << i) : 0u;
@@ -1355,19 +1360,19 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
         unsigned char* Bs = As + A_BYTES;
         if (edge_t[SET]) {                               // block-uniform
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[SET][i] = and4(ra[SET][i], 0u - ((okmask >> i) & 1u));
+            for (int i = 0; i < NI; ++i) ra[SET][i] = and4(ra[SET][i], 0u - ((okmask >> i) & 1u));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb[SET][i] = and4(rb[SET][i], 0u - ((okmask >> (4 + i)) & 1u));
+            for (int i = 0; i < NI; ++i) rb[SET][i] = and4(rb[SET][i], 0u - ((okmask >> (4 + i)) & 1u));
             rb4[SET] = and4(rb4[SET], 0u - ((okmask >> 8) & 1u));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + wg_swz(sr + 16 * i, sc)) = ra[SET][i];
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(As + wg_swz(sr + RS * i, sc)) = ra[SET][i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 16 * i, sc)) = rb[SET][i];
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + RS * i, sc)) = rb[SET][i];
         if (x5) *reinterpret_cast<uint4*>(Bs + wg_swz(sr + 64, sc)) = rb4[SET];
         if (do_bias) {                                   // bias gradient rides on the dY tile already in registers
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const uint32_t* u32 = reinterpret_cast<const uint32_t*>(&ra[SET][i]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1377,37 +1382,39 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
             }
         }
     };
-    f32x16 acc[NT][2][2];
+    f32x16 acc[NT][2][NBC];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NBC; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
     const int li = lane & 15, g = lane >> 4, h = g >> 1;
     const int rrow = 8 * h + (li >> 2);
     const int acol = wm * 64 + 16 * (g & 1) + 4 * (li & 3);
-    const int bcol = wn * 64 + 16 * (g & 1) + 4 * (li & 3);
+    const int bcol = wn * (32 * NBC) + 16 * (g & 1) + 4 * (li & 3);
     typedef __attribute__((address_space(3))) s16x4* lds_s4;
     // per-lane LDS byte offsets of the transposing reads, computed ONCE: sub-step ks adds 16 rows = 4096 B and the
     // buffer index adds a constant, both of which (row & 3 unchanged) fold into the ds_read immediate offset.
     auto tr_off = [&](int row, int col) -> unsigned { return (unsigned)(row * 256 + ((((col >> 5) ^ (row & 3))) << 6) + ((col & 31) << 1)); };
-    unsigned offA[2][2], offB[NT][2][2];                 // [blk][lo/hi], [tap][blk][lo/hi]
+    unsigned offA[2][2], offB[NT][NBC][2];               // [blk][lo/hi], [tap][blk][lo/hi]
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
             offA[blk][hl] = tr_off(rrow + 4 * hl, acol + blk * 32);
+            if (blk < NBC) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) offB[t][blk][hl] = A_BYTES + tr_off(rrow + 4 * hl + t * a.dil, bcol + blk * 32);
+                for (int t = 0; t < NT; ++t) offB[t][blk][hl] = A_BYTES + tr_off(rrow + 4 * hl + t * a.dil, bcol + blk * 32);
+            }
         }
     const unsigned smem_u = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto tr_read = [&](unsigned off) -> s16x4 {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(size_t)(smem_u + off));
     };
-    s16x8 af[2][2], bf[2][NT][2];                        // [set][..]: fragment double buffer
+    s16x8 af[2][2], bf[2][NT][NBC];                      // [set][..]: fragment double buffer
     auto read_frags = [&](int set, int bufoff, int ks) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -1418,7 +1425,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
+            for (int blk = 0; blk < NBC; ++blk) {
                 s16x4 lo = tr_read(offB[t][blk][0] + bufoff + ks * 4096);
                 s16x4 hi = tr_read(offB[t][blk][1] + bufoff + ks * 4096);
                 bf[set][t][blk] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -1430,7 +1437,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NBC; ++nb)
                     acc[t][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, af[set][mb]), __builtin_bit_cast(bf16x8, bf[set][t][nb]), acc[t][mb][nb], 0, 0, 0);
     };
@@ -1477,13 +1484,13 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
         if (tid < 128 && n0 + tid < a.N) {
             float t = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+            for (int r = 0; r < RS; ++r) t += red[r * 128 + tid];
             atomicAdd(a.dbias + n0 + tid, t);
         }
     }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        int c = c0 + wn * 64 + nb * 32 + fl;
+    for (int nb = 0; nb < NBC; ++nb) {
+        int c = c0 + wn * (32 * NBC) + nb * 32 + fl;
         if (c >= a.Cin) continue;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -1500,18 +1507,18 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
 
 // grid.x = (n-tile, c-tile, tap group): the first a.g3 groups take NT taps each, one more group (if REM) the remaining
 // REM taps - k = 9: 3+3+3, k = 5: 3+2, k = 3: 3, k = 1: <1,0> - all in ONE launch (one split-K depth, one set of atomics).
-template <int NT, int REM>
-__global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(WgradArgs a) {
+template <int NT, int REM, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) conv_wgrad_bf16_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [buf][dY 64 rows | X 72 rows][256 B]
     const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
     int bx = blockIdx.x;
     const int tile_n = bx % ntn; bx /= ntn;
     const int tile_c = bx % ntc; bx /= ntc;
-    if (REM == 0 || bx < a.g3) wgrad_bf16_body<NT>(a, smem, tile_n, tile_c, bx * NT);
-    else wgrad_bf16_body<(REM ? REM : 1)>(a, smem, tile_n, tile_c, a.g3 * NT);
+    if (REM == 0 || bx < a.g3) wgrad_bf16_body<NT, NW>(a, smem, tile_n, tile_c, bx * NT);
+    else wgrad_bf16_body<(REM ? REM : 1), NW>(a, smem, tile_n, tile_c, a.g3 * NT);
 }
 
-template <int NT, int REM>
+template <int NT, int REM, int NW>
 static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream) {
     a.S = S_eff;
     a.g3 = g3;
@@ -1519,7 +1526,7 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     a.dbg = dbg;
     const int dyn = 2 * (64 * 256 + 72 * 256);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<NT, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<NT, REM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
     const int groups = g3 + (REM ? 1 : 0);
     long tiles = (long)fs2_cdiv(a.N, 128) * fs2_cdiv(a.Cin, 128) * groups;
     int tps = (a.S + 63) / 64;
@@ -1539,7 +1546,7 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     if (ups < min_ups) ups = min_ups;
     a.rows_per_split = (int)ups;
     dim3 grid((unsigned)tiles, (unsigned)fs2_cdiv(units, ups));
-    conv_wgrad_bf16_kernel<NT, REM><<<grid, 256, dyn, stream>>>(a);
+    conv_wgrad_bf16_kernel<NT, REM, NW><<<grid, 64 * NW, dyn, stream>>>(a);
 }
 
 extern "C" int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, hipStream_t stream);
@@ -1566,12 +1573,19 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) {
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
-        if (fast && taps == 1) { launch_wgrad_bf16<1, 0>(a, (lens && M % S == 0) ? S : M, 1, stream); bias_fused = true; }   // no taps, no lens: one "sequence" of M rows
+        static const int wg_waves = [] { const char* e = getenv("FS2_WGRAD_WAVES"); return e ? atoi(e) : 8; }();   // dev A/B: 4 | 8
+        if (fast && taps == 1) { launch_wgrad_bf16<1, 0, 4>(a, (lens && M % S == 0) ? S : M, 1, stream); bias_fused = true; }   // no taps, no lens: one "sequence" of M rows
         else if (fast && 2 * dil <= 8 && M % S == 0) {
             const int g3 = taps / 3, rem = taps - 3 * g3;
-            if (rem == 0) launch_wgrad_bf16<3, 0>(a, S, g3, stream);
-            else if (rem == 2) launch_wgrad_bf16<3, 2>(a, S, g3, stream);
-            else launch_wgrad_bf16<3, 1>(a, S, g3, stream);
+            if (wg_waves == 8) {
+                if (rem == 0) launch_wgrad_bf16<3, 0, 8>(a, S, g3, stream);
+                else if (rem == 2) launch_wgrad_bf16<3, 2, 8>(a, S, g3, stream);
+                else launch_wgrad_bf16<3, 1, 8>(a, S, g3, stream);
+            } else {
+                if (rem == 0) launch_wgrad_bf16<3, 0, 4>(a, S, g3, stream);
+                else if (rem == 2) launch_wgrad_bf16<3, 2, 4>(a, S, g3, stream);
+                else launch_wgrad_bf16<3, 1, 4>(a, S, g3, stream);
+            }
             bias_fused = true;
         }
         else conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
