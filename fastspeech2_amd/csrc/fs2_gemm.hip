@@ -666,7 +666,10 @@ __device__ __forceinline__ void ring_loader(const ConvGemmArgs& a, unsigned char
 }
 
 // ---- consumer waves (wave = 0..3 as 2 x 2): fragment reads + MFMA
-template <bool ONE_TAP, bool MASK>
+// INACT: leaky-ReLU applied to the activation fragments after they land (HiFi-GAN's pre-activation convs: 7 VALU per
+// dword - widen both halves by shift/mask, max(x, slope*x), hardware bf16 pack - which fits under the wave's MFMAs;
+// the LDS-DMA path cannot transform data on the way in)
+template <bool ONE_TAP, bool MASK, bool INACT>
 __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned char* smem, f32x16 (&acc)[2][2], int m0, int lane,
                                               int wm, int wn) {
     typedef RingCfg<ONE_TAP> C;
@@ -733,6 +736,13 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 u32x4 av = af[set][q][mb];
+                if (INACT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo = __uint_as_float(av[e] << 16), hi = __uint_as_float(av[e] & 0xffff0000u);
+                        av[e] = pack_bf16x2(fmaxf(lo, lo * a.in_slope), fmaxf(hi, hi * a.in_slope));       // 0 < slope < 1
+                    }
+                }
                 if (MASK && !((vmask[mb] >> tap) & 1u)) av = u32x4{0u, 0u, 0u, 0u};     // tap leaves the row's sequence
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
@@ -768,7 +778,7 @@ __device__ __forceinline__ void ring_consumer(const ConvGemmArgs& a, unsigned ch
 #undef FS2_DS_READ_B128
 }
 
-template <bool ONE_TAP>
+template <bool ONE_TAP, bool INACT>
 __global__ void __launch_bounds__(768, 3) conv_gemm_ring_kernel(ConvGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -808,13 +818,13 @@ __global__ void __launch_bounds__(768, 3) conv_gemm_ring_kernel(ConvGemmArgs a) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         if (ONE_TAP) {
-            ring_consumer<true, false>(a, smem, acc, m0, lane, wm, wn);
+            ring_consumer<true, false, INACT>(a, smem, acc, m0, lane, wm, wn);
         } else {
             int t0 = m0 % a.S;
             int rows = min(256, a.M - m0);
             const bool need_mask = (t0 < a.pad) || (t0 + rows - 1 + (a.taps - 1) * a.dil - a.pad >= a.S);
-            if (need_mask) ring_consumer<false, true>(a, smem, acc, m0, lane, wm, wn);
-            else ring_consumer<false, false>(a, smem, acc, m0, lane, wm, wn);
+            if (need_mask) ring_consumer<false, true, INACT>(a, smem, acc, m0, lane, wm, wn);
+            else ring_consumer<false, false, INACT>(a, smem, acc, m0, lane, wm, wn);
         }
     }
     __syncthreads();                                       // every consumer is done reading the operand slots
@@ -1019,7 +1029,8 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     // variant (dev A/B only)
     static const int force_tile = [] { const char* e = getenv("FS2_GEMM_TILE"); return e ? atoi(e) : 0; }();
     const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
-    const bool ring_ok = dtype == FS2_BF16 && in_act == FS2_ACT_NONE && (taps == 1 || (taps >= 3 && (taps - 1) * dil <= 16 && taps <= 32)) &&
+    const bool ring_inact = in_act == FS2_ACT_LRELU && in_slope > 0.f && in_slope < 1.f;
+    const bool ring_ok = dtype == FS2_BF16 && (in_act == FS2_ACT_NONE || ring_inact) && (taps == 1 || (taps >= 3 && (taps - 1) * dil <= 16 && taps <= 32)) &&
                          Cin % 64 == 0 && (double)M * ldx * 2 < 2.0e9 && (double)N * taps * Cin * 2 < 2.0e9;
     // taps == 1 contractions with a short K (4-12 steps) do not amortise the ring's fill: measured faster on the 128^2 kernel
     bool big = ring_ok && big_tiles >= 170 && (taps > 1 || Cin >= 1024);
@@ -1043,12 +1054,17 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
         const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
         const int dynk = RingCfg<false>::B_OFF + RingCfg<false>::D * RING_B_BYTES;
         if (!ring_attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn1);
-            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn1);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn1);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
             ring_attr_set = true;
         }
-        if (taps == 1) conv_gemm_ring_kernel<true><<<(unsigned)big_tiles, 768, dyn1, stream>>>(a);
-        else conv_gemm_ring_kernel<false><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
+        if (ring_inact) {
+            if (taps == 1) conv_gemm_ring_kernel<true, true><<<(unsigned)big_tiles, 768, dyn1, stream>>>(a);
+            else conv_gemm_ring_kernel<false, true><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
+        } else if (taps == 1) conv_gemm_ring_kernel<true, false><<<(unsigned)big_tiles, 768, dyn1, stream>>>(a);
+        else conv_gemm_ring_kernel<false, false><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
     } else if (dma) {
         const int dyn = 2 * 160 * 128 + 2 * 128 * 128;
         static bool attr_set = false;

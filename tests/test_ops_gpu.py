@@ -438,3 +438,21 @@ def test_batchnorm_shapes(dev, M, C):
     dx, dgam, dbet = ops.bn_bwd(x.to(dev), dout.to(dev), mean_rstd, gamma.to(dev), beta.to(dev), ops.ACT_NONE, 0.0, 0)
     assert rel_err(dx, xr.grad) < 2e-3
     assert rel_err(dgam, gr.grad) < 2e-3 and rel_err(dbet, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,S,C,N,k,dil", [(48, 925, 128, 128, 11, 1), (12, 4000, 256, 256, 3, 3), (24, 2000, 1024, 256, 1, 1)])
+def test_conv_gemm_big_tile_lrelu_prologue(dev, B, S, C, N, k, dil):
+    """leaky-ReLU prologue on the 256x128 ring kernel (applied to the fragments after the LDS-DMA) == activation applied
+    beforehand in bf16 (HiFi-GAN's pre-activation convolutions at the 128/256-channel stages)."""
+    ops = _ops()
+    torch.manual_seed(41)
+    M = B * S
+    x = torch.randn(M, C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, k, C, device=dev) / (C * k) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=dev)
+    pad = dil * (k - 1) // 2
+    got = ops.conv_gemm(x, w, b, S, taps=k, dil=dil, pad=pad, in_act=ops.ACT_LRELU, in_slope=0.1)
+    xl = torch.nn.functional.leaky_relu(x.float(), 0.1).to(torch.bfloat16)
+    ref = ops.conv_gemm(xl, w, b, S, taps=k, dil=dil, pad=pad)
+    # both calls take the ring kernel (>= 170 tiles): same accumulation order, same bf16 rounding of the activation
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
