@@ -1,0 +1,35 @@
+"""bench.py's output contract (GPU): ONE JSON line with the metric BASELINE.json names, whole-job value, the roofline object
+(dominant kernel, live HIP-event timing, algorithmic FLOPs) and the cpu_baseline object (oracle on the host cores)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract(dev):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("mel-frames/sec") and d["unit"] == "mel-frames/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    frames_per_step = d["value"] * d["ms_per_step"] * 1e-3                  # value = valid frames per step / step time
+    assert d["value"] > 1e5 and 0.75 * 48 * 925 < frames_per_step <= 48 * 925 * 1.001, frames_per_step
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"]["bytes_per_launch"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "mel-frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 100 * c["value"]
