@@ -340,23 +340,29 @@ def main():
         prof, ops.PROFILE = ops.PROFILE, None
         model._engine.use_side_stream = side
         rec = prof.get("conv_gemm", [])
-        ms = sum(e0.elapsed_time(e1) for (_, e0, e1) in rec)
-        fl = sum(f for (f, _, _) in rec)
-        if ms > 0:
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel"}
+        by = {}
+        for (f, e0, e1, var) in rec:
+            d = by.setdefault(var, [0.0, 0.0, 0])
+            d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
+        tot_ms = sum(d[1] for d in by.values())
+        if tot_ms > 0:
+            # the DOMINANT kernel = the conv_gemm variant with the largest share of the step (the 256x128 ring kernel: k=9 FFN
+            # conv and k=5 PostNet conv, forward + data gradient); its rocprofv3 row is `conv_gemm_ring_kernel<...>`
+            dom = max(by, key=lambda v: by[v][1])
+            fl, ms, n = by[dom]
             ach = fl / (ms * 1e-3) / 1e12
-            peak = MFMA_PEAK_TFLOPS[args.dtype]
-            # the big launches (>= 50 GFLOP: k=9 FFN conv and k=5 PostNet conv, forward + data gradient) are the ones the
-            # ring kernel runs; they are the single largest time block of the step
-            big = [(f, e0.elapsed_time(e1)) for (f, e0, e1) in rec if f >= 5e10]
-            big_ach = sum(f for f, _ in big) / (sum(t for _, t in big) * 1e-3) / 1e12 if big else None
-            roofline = {"bound": "mfma", "kernel": "fs2_conv_gemm family (conv_gemm_ring_kernel / conv_gemm_dma_kernel / conv_gemm_kernel, %s)" % args.dtype,
+            fam = sum(d[0] for d in by.values()) / (tot_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": names.get(dom, str(dom)) + " (%s)" % args.dtype,
                         "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": pmc_traffic("conv_gemm"),
-                        "launches_per_step": len(rec) // 3, "kernel_ms_per_step": round(ms / 3, 3),
-                        "avg_launch_us": round(ms / len(rec) * 1e3, 1),
-                        "ring_kernel_achieved": round(big_ach, 1) if big_ach else None,
-                        "ring_kernel_frac": round(big_ach / peak, 4) if big_ach else None,
-                        "ring_kernel_ms_per_step": round(sum(t for _, t in big) / 3, 3) if big else None,
+                        "traffic": pmc_traffic(names.get(dom, "conv_gemm")),
+                        "launches_per_step": n // 3, "kernel_ms_per_step": round(ms / 3, 3), "avg_launch_us": round(ms / n * 1e3, 1),
+                        "gflop_per_launch": round(fl / n / 1e9, 1),
+                        "conv_gemm_family": {v2: {"kernel": names.get(v2, str(v2)), "launches_per_step": d[2] // 3,
+                                                  "ms_per_step": round(d[1] / 3, 3), "tflops": round(d[0] / (d[1] * 1e-3) / 1e12, 1)}
+                                             for v2, d in sorted(by.items())},
+                        "family_achieved": round(fam, 1), "family_frac": round(fam / peak, 4), "family_ms_per_step": round(tot_ms / 3, 3),
                         "step_frac_of_peak": round(value / world * TRAIN_FLOP_PER_FRAME / (peak * 1e12), 4)}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -1003,6 +1003,11 @@ static void launch_skinny(const ConvGemmArgs& a, hipStream_t stream) {
     conv_skinny_kernel<C><<<(unsigned)fs2_cdiv(a.M, 128), 256, SkinnyCfg<C>::LDS, stream>>>(a);
 }
 
+// which kernel the calling thread's last fs2_conv_gemm dispatched to (measurement aid: lets bench.py attribute its
+// HIP-event durations to the same kernel names rocprofv3 reports)
+static thread_local int fs2_last_gemm_variant = 0;
+extern "C" int fs2_conv_gemm_last_variant(void) { return fs2_last_gemm_variant; }
+
 extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
                              long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad,
                              int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
@@ -1045,6 +1050,7 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     const int skinny_bit = Cin == 32 ? 1 : (Cin == 64 ? 2 : (in_act == FS2_ACT_NONE ? 4 : 8));
     const bool skinny = (skinny_mask & skinny_bit) && dtype == FS2_BF16 && N == Cin && (Cin == 32 || Cin == 64 || Cin == 128) && taps <= 16 &&
                         (taps - 1) * dil <= 64 && (in_act == FS2_ACT_NONE || in_act == FS2_ACT_LRELU) && a.vec_ok;
+    fs2_last_gemm_variant = skinny ? FS2_GEMM_SKINNY : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN));
     if (skinny) {
         if (Cin == 32) launch_skinny<32>(a, stream);
         else if (Cin == 64) launch_skinny<64>(a, stream);

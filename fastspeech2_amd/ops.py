@@ -113,7 +113,7 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
               taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
     if PROFILE is not None:
         e1.record()
-        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1))
+        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, _lib.load().fs2_conv_gemm_last_variant()))
     return out
 
 

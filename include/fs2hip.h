@@ -45,6 +45,12 @@ int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bia
                   long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad, int act,
                   float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
                   fs2_stream_t stream);
+/* Kernel the calling thread's last fs2_conv_gemm dispatched to (thread-local; a measurement aid for bench.py). */
+#define FS2_GEMM_PLAIN 1   /* conv_gemm_kernel: 128x128 register-staged */
+#define FS2_GEMM_DMA 2     /* conv_gemm_dma_kernel: 128x128 LDS-DMA, halo reuse (incl. in-workgroup split-K) */
+#define FS2_GEMM_RING 3    /* conv_gemm_ring_kernel: 256x128 wave-specialised */
+#define FS2_GEMM_SKINNY 4  /* conv_skinny_kernel: C = 32 / 64 */
+int fs2_conv_gemm_last_variant(void);
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
  * -> Wf[n][j][c] (forward: dtype cast) and/or Wd[c][j][n] = W[n][k-1-j][c] (data gradient: tap flip + transpose). */
 int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, fs2_stream_t stream);
