@@ -84,7 +84,18 @@ def build(args, device, rank, world):
         L = int(pool[1024])
         b = synthetic_batch(1234 + rank, args.batch, L, dur_lo=4, dur_hi=10, min_len_frac=float(pool[1024 + args.batch]) / L, n_speaker=2456)
     else:
-        b = synthetic_batch(1234 + rank, args.batch, args.phonemes, dur_lo=4, dur_hi=10, min_len_frac=0.75)
+        # every rank gets the SAME length profile (what the length-bucketed card-wise sampler of fastspeech2_amd/data.py deals
+        # per step, so no rank waits for another's longer batch) with its OWN contents (phoneme ids, mels, pitch, energy)
+        b = synthetic_batch(1234, args.batch, args.phonemes, dur_lo=4, dur_hi=10, min_len_frac=0.75)
+        if rank > 0:
+            g = torch.Generator().manual_seed(1234 + rank)
+            L, T = b["max_src_len"], b["max_mel_len"]
+            sv = torch.arange(L).unsqueeze(0) < b["src_lens"].unsqueeze(1)
+            mv = (torch.arange(T).unsqueeze(0) < b["mel_lens"].unsqueeze(1)).unsqueeze(-1)
+            b["texts"] = torch.randint(1, 361, (args.batch, L), generator=g) * sv
+            b["mels"] = (torch.clamp(torch.randn(args.batch, T, 80, generator=g) * 2 - 5, -11.5, 2.0) * mv).float()
+            b["pitches"] = (torch.clamp(torch.randn(args.batch, L, generator=g), -2.917, 11.391) * sv).float()
+            b["energies"] = (torch.clamp(torch.randn(args.batch, L, generator=g), -1.431, 8.184) * sv).float()
     b = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     loss_fn = FastSpeech2Loss(pcfg, mcfg, count_reduce=ddp.global_counts if world > 1 else None)
     opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
