@@ -1,5 +1,6 @@
 """CPU: host-side logic above the C ABI that needs no kernel launch — LR schedule, flat parameter layout,
 checkpoint (state_dict) round trip, tap-major weight views."""
+import pytest
 import torch
 
 from oracle import fs2_oracle as O
@@ -66,3 +67,28 @@ def test_checkpoint_round_trip(tmp_path):
     # loading must keep the parameters aliased to the flat buffer
     flat = m2.flat_parameters()
     assert flat.data_ptr() <= m2.mel_linear.weight.data_ptr() < flat.data_ptr() + flat.numel() * 4
+
+
+@pytest.mark.parametrize("tag,kw", [("lj_4_6", dict(dec_layers=6)), ("lj_4_4", dict(dec_layers=4)),
+                                    ("multi_4_4", dict(dec_layers=4, multi_speaker=True)), ("frame_4_4", dict(dec_layers=4, frame_level=True))])
+def test_state_dict_schema_matches_reference(tag, kw):
+    """checkpoint format: key names, shapes, dtypes of state_dict() AND the order of parameters() (torch.optim.Adam's
+    state is indexed by it) equal the live reference's (tests/golden/make_golden_schema.py)."""
+    import json
+    import os
+    from tests.golden import configs
+    from fastspeech2_amd.model import FastSpeech2
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_schema.json")))[tag]
+    m = FastSpeech2(*configs.make(**kw))
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()] == g["state_dict"]
+    assert [[k, bool(p.requires_grad)] for k, p in m.named_parameters()] == g["parameters"]
+
+
+def test_hifigan_schema_matches_reference():
+    import json
+    import os
+    from fastspeech2_amd import hifigan, utils
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_schema.json")))["hifigan_v1"]
+    gen = hifigan.Generator(hifigan.AttrDict(utils.HIFIGAN_V1))
+    # (key order inside a weight-normed layer differs - bias / weight_g / weight_v - which load_state_dict does not care about)
+    assert sorted([k, list(v.shape), str(v.dtype)] for k, v in gen.state_dict().items()) == sorted(g["state_dict"])
