@@ -1559,11 +1559,15 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     //   and at least 8 (1-tap) / 16 (few-tile conv) K-tiles per workgroup when the reduction is long.
     static const int wg_env = [] { const char* e = getenv("FS2_WGRAD_WGS"); return e ? atoi(e) : 0; }();
     static const int ups_env = [] { const char* e = getenv("FS2_WGRAD_MINUPS"); return e ? atoi(e) : 0; }();
-    int wg_target = units < 256 ? 192 : (NT == 1 ? 384 : 768);
+    // 8-wave tap-group kernels (one workgroup per CU): ONE round of <= 256 workgroups.  With two waves per SIMD a workgroup
+    // no longer needs a successor queued behind it to hide its latencies, and every extra split is another full-tile burst
+    // of atomics (r01k sweep: k=9 FFN 294 -> 250 us at 5 splits x 48 tiles, PostNet k=5 201 -> 158 us at 8 x 32).
+    int wg_target = units < 256 ? 192 : (NT == 1 ? 384 : (NW == 8 ? 256 : 768));
     int min_ups = NT == 1 ? 8 : ((tiles <= 8 && units >= 512) ? 16 : 4);
     if (wg_env) wg_target = wg_env;
     if (ups_env) min_ups = ups_env;
-    long want = (wg_target + tiles - 1) / tiles;
+    long want = (NW == 8 && NT > 1) ? (wg_target / tiles) : (wg_target + tiles - 1) / tiles;   // floor: never spill into a second round
+    if (want < 1) want = 1;
     long ups = (units + want - 1) / want;
     if (ups < min_ups) ups = min_ups;
     a.rows_per_split = (int)ups;
