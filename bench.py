@@ -174,10 +174,7 @@ def synth_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    device = init_rank(world, local_rank)
     pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
     torch.manual_seed(1234)
     model = FastSpeech2(pcfg, mcfg, compute_dtype=args.dtype)
@@ -233,6 +230,25 @@ def synth_main(args):
         dist.destroy_process_group()
 
 
+def init_rank(world, local_rank):
+    """One process per GPU: bind this rank to its device and join the RCCL group (backend "nccl" is RCCL on ROCm).
+    FS2_BENCH_BACKEND=gloo + FS2_BENCH_SHARE_GPU=1 exist only so that the N>1 code path can be exercised by the tests on a
+    1-GPU box (RCCL refuses two ranks on one device); the driver's launch never sets them."""
+    import torch.distributed as dist
+    share = os.environ.get("FS2_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("FS2_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return device
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the roofline kernel family, from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE, collected in separate runs by tools/pmc_traffic.py; counters cannot be read live here)."""
@@ -259,11 +275,7 @@ def main():
         print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+    device = init_rank(world, local_rank)
 
     from fastspeech2_amd import ddp, ops
     if args.main_prio != 0:
@@ -344,9 +356,16 @@ def main():
         # (single stream for this replay: a kernel's event-bracketed duration is only its own when nothing runs beside it)
         side = model._engine.use_side_stream
         model._engine.use_side_stream = False
+        replay = step
+        if world > 1:
+            # the other ranks are past the timed region: replay a LOCAL step (no gradient exchange, local loss counts) so that
+            # rank 0 never enters a collective alone; kernel shapes and launches are the same
+            model._engine.grad_hook = None
+            loss_fn.count_reduce = None
+            replay, _ = make_step(model, loss_fn, opt, b, None)
         ops.PROFILE = {}
         for _ in range(3):
-            step()
+            replay()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         model._engine.use_side_stream = side
@@ -376,7 +395,7 @@ def main():
                         "family_achieved": round(fam, 1), "family_frac": round(fam / peak, 4), "family_ms_per_step": round(tot_ms / 3, 3),
                         "step_frac_of_peak": round(value / world * TRAIN_FLOP_PER_FRAME / (peak * 1e12), 4)}
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only (host cores are shared by the ranks)
         cpu = cpu_baseline(args)
 
     if rank == 0:
@@ -394,8 +413,9 @@ def main():
                        "side_stream_wgrad": bool(model._engine.use_side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                     # ranks leave together (rank 0 was still replaying for the roofline)
         dist.destroy_process_group()
 
 

@@ -35,3 +35,23 @@ def test_bench_line_contract(dev):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "mel-frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 100 * c["value"]
+
+
+def test_bench_two_ranks_shared_gpu(dev):
+    """The N>1 launch the driver uses (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`), exercised with two
+    ranks on this box's single GPU: gloo instead of RCCL (RCCL refuses two ranks on one device), everything else — gradient
+    exchange hooks, global loss counts, barrier + max-over-ranks timing, rank 0's local roofline replay, joint exit — as shipped."""
+    env = dict(os.environ, FS2_BENCH_BACKEND="gloo", FS2_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 96
+    assert d["config"]["parallelism"] == "dp2"
+    frames_per_step = d["value"] * d["ms_per_step"] * 1e-3                  # whole-job: both ranks' valid frames
+    assert 2 * 0.75 * 48 * 925 < frames_per_step <= 2 * 48 * 925 * 1.001, frames_per_step
+    assert d["roofline"]["kernel"].startswith("conv_gemm_ring_kernel") and d["roofline"]["launches_per_step"] == 24
+    assert d["cpu_baseline"] is None                                        # reported at N=1 only
