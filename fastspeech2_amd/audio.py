@@ -97,11 +97,34 @@ class TacotronSTFT(torch.nn.Module):
             self.to(y.device)
         y = y.contiguous().float()
         B, N = y.shape
+        return self._framed_mel(y, B, N, None)
+
+    def mel_spectrogram_ragged(self, y, lens):
+        """Corpus form of `mel_spectrogram` (preprocessor/preprocessor.py:194 calls it once per utterance): y (B, Nmax) holds
+        B utterances of `lens[b]` samples each (anything beyond is ignored).  Every row is reflected at its OWN end, so
+        frames [0, lens[b] // hop + 1) of row b are bit-identical to the utterance processed alone; later frames are padding.
+        Returns (mel (B, n_mel, Nmax // hop + 1), energy (B, Nmax // hop + 1), frames (B,) int64)."""
+        if not y.is_cuda:
+            raise RuntimeError("fastspeech2_amd.audio.TacotronSTFT runs on an AMD GPU only (no CPU fallback)")
+        if self.forward_basis.device != y.device:
+            self.to(y.device)
+        y = y.contiguous().float()
+        B, N = y.shape
+        lens = torch.as_tensor(lens, device=y.device).to(torch.int32).contiguous()
+        assert lens.numel() == B and int(lens.max()) <= N and int(lens.min()) > self.filter_length // 2, \
+            "each utterance needs more than filter_length/2 samples (reflect padding) and must fit its row"
+        mel, energy = self._framed_mel(y, B, N, lens)
+        return mel, energy, lens.to(torch.int64) // self.hop_length + 1
+
+    def _framed_mel(self, y, B, N, lens):
         hop, taps, P = self.hop_length, self.filter_length // self.hop_length, self.filter_length // 2
         frames = N // hop + 1
         S = frames + taps - 1                                               # rows of `hop` samples per utterance
         xp = torch.empty(B, S * hop, device=y.device, dtype=torch.float32)
-        _lib.call("fs2_reflect_pad", y.data_ptr(), xp.data_ptr(), B, N, P, S * hop, ops._stream())
+        if lens is None:
+            _lib.call("fs2_reflect_pad", y.data_ptr(), xp.data_ptr(), B, N, P, S * hop, ops._stream())
+        else:
+            _lib.call("fs2_reflect_pad_ragged", y.data_ptr(), N, lens.data_ptr(), xp.data_ptr(), B, P, S * hop, ops._stream())
         nft = 2 * self.cutoff
         ft = torch.empty(B * S, (nft + 3) // 4 * 4, device=y.device, dtype=torch.float32)[:, :nft]   # 16-B aligned rows
         ops.conv_gemm(xp.view(B * S, hop), self.forward_basis, None, S, taps=taps, pad=0, out=ft)

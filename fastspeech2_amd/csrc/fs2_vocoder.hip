@@ -118,6 +118,34 @@ extern "C" int fs2_reflect_pad(const float* y, float* xp, int B, int N, int P, l
     return FS2_OK;
 }
 
+// Ragged batch (corpus preprocessing): utterance b has its own length lens[b] (row stride ldy in y); each row is reflected at
+// ITS end and zero-filled beyond, so frame t < lens[b]/hop + 1 of row b equals the frame of the utterance processed alone.
+__global__ void reflect_pad_ragged_kernel(const float* __restrict__ y, long ldy, const int32_t* __restrict__ lens,
+                                          float* __restrict__ xp, int P, long row_len) {
+    int b = blockIdx.y;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_len) return;
+    const long N = lens[b];
+    float v = 0.f;
+    if (N > P && i < N + 2 * P) {
+        long s = i - P;
+        if (s < 0) s = -s;
+        if (s >= N) s = 2L * (N - 1) - s;
+        v = y[(size_t)b * ldy + s];
+    }
+    xp[(size_t)b * row_len + i] = v;
+}
+extern "C" int fs2_reflect_pad_ragged(const float* y, long ldy, const int32_t* lens, float* xp, int B, int P, long row_len,
+                                      hipStream_t stream) {
+    FS2_CHECK_ARG(y && xp && lens, "reflect_pad_ragged: null pointer");
+    FS2_CHECK_ARG(B >= 0 && P >= 0 && row_len > 0 && ldy > 0, "reflect_pad_ragged: bad shape P=%d row_len=%ld ldy=%ld", P, row_len, ldy);
+    if (B == 0) return FS2_OK;
+    dim3 grid(fs2_cdiv(row_len, 256), B);
+    reflect_pad_ragged_kernel<<<grid, 256, 0, stream>>>(y, ldy, lens, xp, P, row_len);
+    FS2_CHECK_LAUNCH("reflect_pad_ragged");
+    return FS2_OK;
+}
+
 // ------------------------------------------------------------------ |DFT| -> mel -> log ; energy
 // ft rows [B*S][2*NF] = (Re[0..NF) | Im[0..NF)) from the framed-DFT GEMM; only rows t < frames of each utterance
 // are frames.  A 256-thread block owns FR = 16 frames: magnitudes go to LDS once ([FR][NF] f32), energy is a wave

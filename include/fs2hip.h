@@ -160,6 +160,10 @@ int fs2_conv_post_pcm(const void* x, long ldx, const float* w, const float* bias
                       fs2_stream_t stream);
 /* stft.py:60-66: xp[b][i] = y[b][reflect(i - P)], i < N + 2P; zero-filled up to row_len. */
 int fs2_reflect_pad(const float* y, float* xp, int B, int N, int P, long row_len, fs2_stream_t stream);
+/* The same for a ragged batch (preprocessor/preprocessor.py:194 over a corpus): row b holds lens[b] samples (row stride ldy,
+ * lens[b] > P else the row is zero-filled) and is reflected at its own end. */
+int fs2_reflect_pad_ragged(const float* y, long ldy, const int32_t* lens, float* xp, int B, int P, long row_len,
+                           fs2_stream_t stream);
 /* stft.py:74-78,174-176 + audio_processing.py:91: ft rows [B*S][2*NF] (Re|Im) -> mel (B, n_mel, frames) =
  * log(clamp(mel_basis[n_mel][NF] . |ft|, clamp_min)), energy (B, frames) = ||ft|||_2; span[n_mel][2] = non-zero
  * band [lo, hi) of each filter. */

@@ -74,3 +74,92 @@ def make_preprocessed_dir(root, seed=77, n_train=11, n_val=5, n_mel=80, speakers
         with open(os.path.join(root, fname), "w", encoding="utf-8") as f:
             f.write("\n".join(lines) + "\n")
     return root
+
+
+# ---------------------------------------------------------------------------------------------- raw corpus (preprocessor tests)
+def fake_pitch(wav, sampling_rate, hop_length):
+    """Deterministic stand-in for pyworld dio + stonemask (absent from this image): one value per frame (len // hop + 1 frames,
+    as DIO yields), 0 = unvoiced where the frame's RMS is below 0.01, else a smooth contour.  Used identically by the golden
+    generator (stubbed into the reference as `pyworld`) and by the tests (passed as `pitch_fn`)."""
+    wav = np.asarray(wav, dtype=np.float64)
+    n = len(wav) // hop_length + 1
+    pad = np.concatenate([wav, np.zeros(n * hop_length - len(wav))])
+    rms = np.sqrt((pad.reshape(n, hop_length) ** 2).mean(axis=1))
+    i = np.arange(n)
+    f0 = 140.0 + 45.0 * np.sin(i / 5.0) + 20.0 * np.cos(i / 1.7) + 300.0 * rms
+    return np.where(rms >= 0.01, f0, 0.0)
+
+
+def make_raw_corpus(root, seed=5, sr=22050, hop=256):
+    """A tiny raw corpus + MFA-style alignments in the layout preprocessor/preprocessor.py:66-79,155-160 walks:
+    `{root}/raw/{speaker}/{name}.wav|.lab`, `{root}/pre/TextGrid/{speaker}/{name}.TextGrid`.
+    Cases: leading / trailing / inner silences, a zero-frame phone, a wav without TextGrid (stale-statistics quirk),
+    an all-silence alignment (start >= end -> skipped), a near-silent recording (<= 1 voiced frame -> skipped), a short-format
+    TextGrid with an empty interval.  Returns (preprocess config dict, {(speaker, name): [(start, end, phone), ...]})."""
+    import os
+    from scipy.io import wavfile
+
+    rng = np.random.RandomState(seed)
+    raw, pre = os.path.join(root, "raw"), os.path.join(root, "pre")
+    plan = {
+        ("spkA", "a1"): ["sil", "DH", "AH0", "sp", "K", "AE1", "T", "sp"],
+        ("spkA", "a2"): ["HH", "AH0", "L", "OW1", "sp", "W", "ER1", "L", "D", "sil"],
+        ("spkA", "a3"): None,                                   # wav + lab but no TextGrid
+        ("spkA", "a4"): ["sil", "sp", "sil"],                   # nothing but silence
+        ("spkB", "b1"): ["sp", "S", "IH1", "K", "S", "spn", "T", "IY1", "N"],
+        ("spkB", "b2"): ["T", "EH1", "S", "T"],                 # near-silent audio: no voiced frames
+        ("spkB", "b3"): ["sil", "M", "AO1", "R", "", "F", "AY1", "V", "sil"],    # short format, "" interval dropped by the reader
+    }
+    tables = {}
+    for (spk, name), phones in plan.items():
+        os.makedirs(os.path.join(raw, spk), exist_ok=True)
+        os.makedirs(os.path.join(pre, "TextGrid", spk), exist_ok=True)
+        n_ph = len(phones) if phones else 6
+        lens = rng.uniform(0.03, 0.22, size=n_ph)
+        if name == "a2":
+            lens[2] = 0.0009                                    # rounds to a zero-frame phone
+        bounds = np.round(np.concatenate([[0.0], np.cumsum(lens)]), 4)
+        total = float(bounds[-1]) + 0.05
+        t = np.arange(int(total * sr)) / sr
+        wav = 0.001 * rng.randn(len(t))
+        for k in range(n_ph):
+            p = phones[k] if phones else "AH0"
+            if p in ("sil", "sp", "spn", ""):
+                continue
+            m = (t >= bounds[k]) & (t < bounds[k + 1])
+            f = rng.uniform(100, 320)
+            amp = 0.002 if name == "b2" else rng.uniform(0.15, 0.45)
+            wav[m] += amp * (np.sin(2 * np.pi * f * t[m]) + 0.4 * np.sin(2 * np.pi * 3.1 * f * t[m]) + 0.1 * rng.randn(m.sum()))
+        wavfile.write(os.path.join(raw, spk, name + ".wav"), sr, (np.clip(wav, -1, 1) * 32767).astype(np.int16))
+        with open(os.path.join(raw, spk, name + ".lab"), "w") as f:
+            f.write("raw text of %s\n" % name)
+        if phones is None:
+            continue
+        iv = [(float(bounds[k]), float(bounds[k + 1]), phones[k]) for k in range(n_ph)]
+        tables[(spk, name)] = [x for x in iv if x[2] != ""]
+        words = [(0.0, float(bounds[-1]), "w")]
+        path = os.path.join(pre, "TextGrid", spk, name + ".TextGrid")
+        with open(path, "w") as f:
+            if name == "b3":                                    # Praat "short" text format
+                f.write('File type = "ooTextFile"\nObject class = "TextGrid"\n\n0\n%r\n<exists>\n2\n' % float(bounds[-1]))
+                for tier, items in (("words", words), ("phones", iv)):
+                    f.write('"IntervalTier"\n"%s"\n0\n%r\n%d\n' % (tier, float(bounds[-1]), len(items)))
+                    for s, e, p in items:
+                        f.write('%r\n%r\n"%s"\n' % (s, e, p))
+            else:
+                f.write('File type = "ooTextFile"\nObject class = "TextGrid"\n\nxmin = 0 \nxmax = %r \ntiers? <exists> \nsize = 2 \nitem []: \n'
+                        % float(bounds[-1]))
+                for ti, (tier, items) in enumerate((("words", words), ("phones", iv))):
+                    f.write('    item [%d]:\n        class = "IntervalTier" \n        name = "%s" \n        xmin = 0 \n        xmax = %r \n'
+                            '        intervals: size = %d \n' % (ti + 1, tier, float(bounds[-1]), len(items)))
+                    for k, (s, e, p) in enumerate(items):
+                        f.write('        intervals [%d]:\n            xmin = %r \n            xmax = %r \n            text = "%s" \n'
+                                % (k + 1, s, e, p))
+    cfg = {"dataset": "Synth", "path": {"raw_path": raw, "preprocessed_path": pre},
+           "preprocessing": {"val_size": 2, "text": {"text_cleaners": ["english_cleaners"], "language": "en"},
+                             "audio": {"sampling_rate": sr, "max_wav_value": 32768.0},
+                             "stft": {"filter_length": 1024, "hop_length": hop, "win_length": 1024},
+                             "mel": {"n_mel_channels": 80, "mel_fmin": 0, "mel_fmax": 8000},
+                             "pitch": {"feature": "phoneme_level", "normalization": True},
+                             "energy": {"feature": "phoneme_level", "normalization": True}}}
+    return cfg, tables
