@@ -36,27 +36,33 @@ class GradExchange:
         self.sent = 0          # prefix [0, sent) already handed to the collective
         self.handles = []
 
-    def _launch(self, lo, hi):
+    def _launch(self, lo, hi, producers=()):
         view = self.flat[lo:hi]
         if self.cuda and self.overlap:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            for s in producers:                 # e.g. the engine's weight-gradient stream: only the collective waits for it
+                self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
                 view.div_(self.world)
                 h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
+            if self.cuda:
+                for s in producers:
+                    torch.cuda.current_stream().wait_stream(s)
             view.div_(self.world)
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)
 
-    def ready(self, end):
-        """Engine hook: gradients in flat[0:end) are final.  Launch every full bucket inside that prefix."""
+    def ready(self, end, producers=()):
+        """Engine hook: gradients in flat[0:end) are final once the work queued so far on the current stream and on every
+        stream in `producers` has run.  Launch every full bucket inside that prefix."""
         if self.world == 1:
             return
         end = min(end, self.n)
         while end - self.sent >= self.bucket_elems:
-            self._launch(self.sent, self.sent + self.bucket_elems)
+            self._launch(self.sent, self.sent + self.bucket_elems, producers)
             self.sent += self.bucket_elems
 
     def finish(self):

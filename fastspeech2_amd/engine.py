@@ -45,7 +45,7 @@ class Engine:
         self.P = dict(model.named_parameters())
         self.Bf = dict(model.named_buffers())
         self.G = None   # name -> grad view (built lazily)
-        self.grad_hook = None   # callable(end_offset): flat_grad[0:end_offset) is final (see ddp.GradExchange.ready)
+        self.grad_hook = None   # callable(end_offset, producer_streams): flat_grad[0:end_offset) is final (see ddp.GradExchange.ready)
         import os
         self.use_side_stream = os.environ.get("FS2_SIDE_STREAM", "1") != "0"
         self._skip_wgrad = os.environ.get("FS2_SKIP_WGRAD", "0") == "1"
@@ -183,9 +183,12 @@ class Engine:
         return self._pe_cache[key]
 
     def _ready(self, next_name):
+        """flat_grad[0:offset(next_name)) is final once the work queued so far on the main AND the side stream is done.  The
+        hook gets the side stream as a `producer`: the exchange makes its COMMUNICATION stream wait for it when (and only
+        when) it launches a bucket — the main stream never waits for weight gradients at a layer boundary."""
         if self.grad_hook is not None:
-            self._side_join()                   # the prefix must be final on the stream the exchange synchronises with
-            self.grad_hook(self.m._flat_offsets[next_name] if next_name else self.m._flat.numel())
+            end = self.m._flat_offsets[next_name] if next_name else self.m._flat.numel()
+            self.grad_hook(end, (self._side,) if self._side is not None else ())
 
     # ------------------------------------------------------------------ building blocks
     def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
