@@ -850,8 +850,8 @@ extern "C" int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
     const int dyn = 163840;
     if (dtype == FS2_F32) {
         attn_delta_kernel<float><<<fs2_cdiv(rows * H, 4), 256, 0, stream>>>((const float*)ctx, (const float*)dctx, delta, rows, S, H);
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
+        static Fs2DevOnce once;
+        once.run([&] { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
         attn_bwd_dkv_kernel<float><<<grid, 256, dyn, stream>>>((const float*)qkv, ld, (const float*)dctx, ldo, lse, delta, (float*)dqkv, lens, S, H, scale);
         attn_bwd_dq_kernel<float><<<grid, 256, 0, stream>>>((const float*)qkv, ld, (const float*)dctx, ldo, lse, delta, (float*)dqkv, lens, S, H, scale);
     } else if (dtype == FS2_BF16) {

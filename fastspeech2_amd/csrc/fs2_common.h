@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 
 #define FS2_OK 0
 #define FS2_EINVAL (-1)    // bad shape / null pointer / unsupported combination
@@ -25,6 +26,22 @@ void fs2_set_error(const char* fmt, ...);
             return FS2_EINVAL;                  \
         }                                       \
     } while (0)
+
+// One-time, PER-DEVICE host-side setup of a kernel (dynamic-LDS opt-in via hipFuncSetAttribute is a per-device property):
+//   static Fs2DevOnce once;  once.run([&] { hipFuncSetAttribute(...); });
+// Thread-safe (autograd / DDP hook threads call the ABI concurrently); the uncontended cost is one mutex + hipGetDevice.
+struct Fs2DevOnce {
+    std::mutex mu;
+    uint64_t done = 0;
+    template <typename F>
+    void run(F&& f) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const uint64_t bit = 1ull << (d & 63);
+        std::lock_guard<std::mutex> g(mu);
+        if (!(done & bit)) { f(); done |= bit; }
+    }
+};
 
 #define FS2_CHECK_LAUNCH(name)                                                        \
     do {                                                                              \

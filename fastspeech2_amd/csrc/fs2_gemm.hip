@@ -998,8 +998,8 @@ __global__ void __launch_bounds__(256) conv_skinny_kernel(ConvGemmArgs a) {
 
 template <int C>
 static void launch_skinny(const ConvGemmArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_skinny_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, SkinnyCfg<C>::LDS); attr_set = true; }
+    static Fs2DevOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_skinny_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, SkinnyCfg<C>::LDS); });
     conv_skinny_kernel<C><<<(unsigned)fs2_cdiv(a.M, 128), 256, SkinnyCfg<C>::LDS, stream>>>(a);
 }
 
@@ -1056,16 +1056,15 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
         else if (Cin == 64) launch_skinny<64>(a, stream);
         else launch_skinny<128>(a, stream);
     } else if (big) {
-        static bool ring_attr_set = false;
+        static Fs2DevOnce ring_once;
         const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
         const int dynk = RingCfg<false>::B_OFF + RingCfg<false>::D * RING_B_BYTES;
-        if (!ring_attr_set) {
+        ring_once.run([&] {
             (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn1);
             (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
             (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn1);
             (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
-            ring_attr_set = true;
-        }
+        });
         if (ring_inact) {
             if (taps == 1) conv_gemm_ring_kernel<true, true><<<(unsigned)big_tiles, 768, dyn1, stream>>>(a);
             else conv_gemm_ring_kernel<false, true><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
@@ -1073,13 +1072,12 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
         else conv_gemm_ring_kernel<false, false><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
     } else if (dma) {
         const int dyn = 2 * 160 * 128 + 2 * 128 * 128;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static Fs2DevOnce dma_once;
+        dma_once.run([&] {
             (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
             (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
             (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn);
-            attr_set = true;
-        }
+        });
         // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
         static const int ksplit_on = [] { const char* e = getenv("FS2_GEMM_KSPLIT"); return e ? atoi(e) : 1; }();
         const int nkc64 = Cin / 64;
@@ -1547,8 +1545,8 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     static const int dbg = [] { const char* e = getenv("FS2_WGRAD_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     const int dyn = 2 * (64 * 256 + 72 * 256);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<NT, REM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); attr_set = true; }
+    static Fs2DevOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<NT, REM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
     const int groups = g3 + (REM ? 1 : 0);
     long tiles = (long)fs2_cdiv(a.N, 128) * fs2_cdiv(a.Cin, 128) * groups;
     int tps = (a.S + 63) / 64;

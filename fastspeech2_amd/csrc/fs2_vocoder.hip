@@ -191,8 +191,8 @@ extern "C" int fs2_stft_mel_epilogue(const float* ft, long ldft, const float* me
                   "stft_mel_epilogue: bad shape S=%d frames=%d NF=%d", S, frames, NF);
     if (B == 0) return FS2_OK;
     size_t lds = (size_t)STFT_FR * NF * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 4); attr_set = true; }
+    static Fs2DevOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * 4); });
     dim3 grid(fs2_cdiv(frames, STFT_FR), B);
     stft_mel_kernel<<<grid, 256, lds, stream>>>(ft, ldft, mel_basis, span, mel, energy, S, frames, NF, n_mel, clamp_min);
     FS2_CHECK_LAUNCH("stft_mel_epilogue");
