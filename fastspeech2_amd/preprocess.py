@@ -222,6 +222,7 @@ class Preprocessor:
         self.pitch_fn = pitch_fn
         self.batch_samples = int(batch_seconds * self.sampling_rate)
         self.num_workers = num_workers
+        self.host_chunk = max(64, 8 * num_workers)          # utterances handed to the host thread pool at a time
         self.seed = seed
         self._staging = None
 
@@ -355,28 +356,42 @@ class Preprocessor:
                 basename = wav_name.split(".")[0]
                 entries.append((speaker, basename, os.path.exists(self._tg_path(speaker, basename))))
 
+        # the corpus streams through in windows of a few device batches of audio, so host memory holds one window of waveforms
+        # (not the corpus: LibriTTS is ~185 GB of float32 samples); per-utterance results kept for the statistics are tiny
         todo = [k for k, e in enumerate(entries) if e[2]]
+        results = {}                                                        # entry index -> _finish_utterance tuple, or None
+        window, window_samples = [], 0
+
+        def flush():
+            items = [it for _, it in window]
+            for batch in self._batches(items):
+                for i, (mel, energy) in zip(batch, self._extract_mels([items[i]["wav"] for i in batch])):
+                    items[i]["wav"] = None                                  # release the audio once its features exist
+                    results[window[i][0]] = self._finish_utterance(items[i], mel, energy)
+            window.clear()
+
         with ThreadPoolExecutor(max_workers=max(1, self.num_workers)) as pool:
-            staged = list(pool.map(lambda k: self._host_stage(entries[k][0], entries[k][1]), todo))
-        live = [(k, it) for k, it in zip(todo, staged) if it is not None]
-        items = [it for _, it in live]
-        feats = [None] * len(items)
-        for batch in self._batches(items):
-            for i, f in zip(batch, self._extract_mels([items[i]["wav"] for i in batch])):
-                feats[i] = f
-                items[i]["wav"] = None                                      # release the audio once its features exist
-        results = {}
-        for (k, it), (mel, energy) in zip(live, feats):
-            results[k] = self._finish_utterance(it, mel, energy)
+            chunk = self.host_chunk
+            for c0 in range(0, len(todo), chunk):
+                ks = todo[c0:c0 + chunk]
+                for k, it in zip(ks, pool.map(lambda k: self._host_stage(entries[k][0], entries[k][1]), ks)):
+                    if it is None:
+                        results[k] = None
+                        continue
+                    window.append((k, it))
+                    window_samples += len(it["wav"])
+                if window_samples >= 4 * self.batch_samples:
+                    flush()
+                    window_samples = 0
+            flush()
 
         # running statistics in corpus order, with the reference's stale-value behaviour for wavs that have no TextGrid
         out, n_frames = [], 0
         pitch_scaler, energy_scaler = RunningMoments(), RunningMoments()
         last = None
-        staged_by_entry = dict(zip(todo, staged))
         for k, (speaker, basename, has_tg) in enumerate(entries):
             if has_tg:
-                if staged_by_entry[k] is None:
+                if results[k] is None:
                     continue                                                # preprocessor.py:80-81
                 last = results[k]
                 out.append(last[0])

@@ -70,6 +70,25 @@ def test_preprocessor_matches_reference_golden(tmp_path, monkeypatch, tag):
     check_against_golden(cfg, out, tag, mel_atol=2e-4)
 
 
+def test_corpus_streams_through_windows(tmp_path, monkeypatch):
+    """host memory holds one window of waveforms: with a tiny window the corpus takes several flushes and the outputs do not change."""
+    flushes = []
+
+    class Windowed(OraclePreprocessor):
+        def _extract_mels(self, wavs):
+            flushes.append(len(wavs))
+            return super()._extract_mels(wavs)
+
+    cfg, tables = make_raw_corpus(str(tmp_path))
+    real = os.listdir
+    monkeypatch.setattr(os, "listdir", lambda p: sorted(real(p)))
+    pp = Windowed(cfg, pitch_fn=fake_pitch, seed=3, device="cpu", num_workers=2, batch_seconds=0.2)
+    pp.host_chunk = 2
+    out = pp.build_from_path()
+    assert sum(flushes) == 4 and len(flushes) >= 3, flushes
+    check_against_golden(cfg, out, "phoneme", mel_atol=2e-4)
+
+
 def test_textgrid_reader_long_and_short_formats(tmp_path):
     cfg, tables = make_raw_corpus(str(tmp_path))
     pre = cfg["path"]["preprocessed_path"]
