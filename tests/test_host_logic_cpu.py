@@ -21,6 +21,43 @@ def test_lr_schedule_matches_oracle():
         assert abs(got - want) <= 1e-12 + 1e-9 * want, step
 
 
+def test_lr_schedule_and_adam_hyperparameters_match_reference_golden():
+    """tests/golden/optim.json: the reference's own ScheduledOptim (model/optimizer.py) after `_update_learning_rate()`."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optim.json")))
+    pcfg, mcfg = configs.make(dec_layers=1, enc_layers=1)
+    oc = configs.TRAIN["optimizer"]
+    for step, want in g["lr"].items():
+        step = int(step)
+        opt = ScheduledOptim(make_model(pcfg, mcfg), configs.TRAIN, mcfg, step - 1)     # restored at step - 1, as get_model does
+        opt.current_step += 1                                                            # what _update_learning_rate does first
+        got = opt.init_lr * opt._get_lr_scale()
+        assert abs(got - want) <= 1e-12 * want + 1e-18, (step, got, want)
+        assert abs(O.lr_at_step(step, 256, oc["warm_up_step"], oc["anneal_steps"], oc["anneal_rate"]) - want) <= 1e-12 * want + 1e-18
+    opt = ScheduledOptim(make_model(pcfg, mcfg), configs.TRAIN, mcfg, 0)
+    assert list(opt.betas) == g["betas"] and opt.eps == g["eps"] and opt.weight_decay == g["weight_decay"]
+    assert abs(opt.init_lr - g["init_lr"]) <= 1e-15
+
+
+@pytest.mark.parametrize("kind", ["linear", "log"])
+def test_quantisation_boundaries_match_reference_golden(tmp_path, kind):
+    """tests/golden/bins.npz: VarianceAdaptor's pitch / energy bins (model/modules.py:41-78) from the reference's constructor."""
+    import json
+    import numpy as np
+    from tests.helpers import load_golden
+    g = load_golden("bins")
+    json.dump(json.loads(str(g["stats"])), open(tmp_path / "stats.json", "w"))
+    pcfg, mcfg = configs.make(dec_layers=1, enc_layers=1)
+    pcfg["path"]["preprocessed_path"] = str(tmp_path)
+    mcfg["variance_embedding"]["pitch_quantization"] = kind
+    mcfg["variance_embedding"]["energy_quantization"] = kind
+    m = make_model(pcfg, mcfg)
+    sd = m.state_dict()
+    assert np.array_equal(sd["variance_adaptor.pitch_bins"].numpy(), g[kind + "_pitch"])       # same torch ops: bit-identical
+    assert np.array_equal(sd["variance_adaptor.energy_bins"].numpy(), g[kind + "_energy"])
+
+
 def test_flat_layout_aliases_every_trainable_parameter():
     pcfg, mcfg = configs.make(dec_layers=2, enc_layers=1, multi_speaker=True)
     m = make_model(pcfg, mcfg)

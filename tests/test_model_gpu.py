@@ -96,7 +96,9 @@ def test_train_grads_match_oracle_elementwise(dev):
 
 
 @pytest.mark.parametrize("tag,B,L,cfg", [("eval_lj", 3, 20, {}),
-                                         ("eval_multi", 2, 12, dict(multi_speaker=True, dec_layers=2, enc_layers=2))])
+                                         ("eval_multi", 2, 12, dict(multi_speaker=True, dec_layers=2, enc_layers=2)),
+                                         # L = 40 and T ~ 500 both beyond max_seq_len = 32: position tables regenerated on the fly
+                                         ("eval_long", 2, 40, dict(dec_layers=2, enc_layers=2, max_seq_len=32))])
 def test_inference_matches_reference_golden(dev, tag, B, L, cfg):
     g = load_golden(tag)
     pcfg, mcfg = configs.make(**cfg)
