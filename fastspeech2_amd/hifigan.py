@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .ops import ACT_LRELU, ACT_NONE
+from .ops import ACT_LRELU
 
 LRELU_SLOPE = 0.1          # hifigan/models.py:7
 

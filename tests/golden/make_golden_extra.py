@@ -15,7 +15,6 @@ import sys
 import tempfile
 
 import numpy as np
-import torch
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))

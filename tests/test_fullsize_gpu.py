@@ -2,7 +2,6 @@
 finishes in seconds (one fp32 eval forward), and size-independent properties where it does not — LengthRegulator against an
 integer restatement, padding invariance, batch-permutation equivariance, replay determinism, linearity of backward in the
 upstream gradient, bf16 against fp32."""
-import numpy as np
 import pytest
 import torch
 

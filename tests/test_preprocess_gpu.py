@@ -1,14 +1,11 @@
 """Corpus preprocessor on the GPU (fastspeech2_amd/preprocess.py + audio.TacotronSTFT.mel_spectrogram_ragged): the same
 synthetic corpus as tests/test_preprocess_cpu.py, mel extraction through the HIP STFT in ragged batches, against the outputs
 of the reference's own preprocessor (tests/golden/preproc_*.npz)."""
-import os
-
 import numpy as np
 import pytest
 import torch
 
 from fastspeech2_amd import preprocess as P
-from tests.helpers import fake_pitch
 from tests.test_preprocess_cpu import _run, check_against_golden
 
 pytestmark = pytest.mark.gpu
