@@ -11,7 +11,7 @@ LIB   := fastspeech2_amd/libfs2hip.so
 
 all: $(LIB)
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -26,3 +26,19 @@ clean:
 	rm -rf build $(LIB)
 
 .PHONY: all clean
+
+# Development build: the same sources with -DFS2_DEV (environment-driven ablation / forced-variant switches compiled IN).
+# Never loaded by the product: tools/ scripts select it with FS2_LIB_PATH=fastspeech2_amd/libfs2hip_dev.so.
+DEVOBJ := build/obj_dev
+DEVOBJS := $(patsubst $(CSRC)/%.hip,$(DEVOBJ)/%.o,$(SRCS)) $(DEVOBJ)/fs2_api.o
+DEVLIB := fastspeech2_amd/libfs2hip_dev.so
+$(DEVOBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h
+	@mkdir -p $(DEVOBJ)
+	$(HIPCC) $(HIPFLAGS) -DFS2_DEV -c $< -o $@
+$(DEVOBJ)/fs2_api.o: $(CSRC)/fs2_api.cpp
+	@mkdir -p $(DEVOBJ)
+	$(HIPCC) -O2 -std=c++17 -fPIC -c $< -o $@
+$(DEVLIB): $(DEVOBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEVOBJS)
+dev: $(DEVLIB)
+.PHONY: dev

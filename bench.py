@@ -58,14 +58,30 @@ def parse():
     ap.add_argument("--vocoder-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dec-layers", type=int, default=4, help="4 = BASELINE's 4+4 (the reported metric); 6 = the reference's stock model.yaml")
     ap.add_argument("--frame-level", action="store_true", help="frame-level pitch/energy (the paper's configuration) instead of phoneme-level")
+    ap.add_argument("--side-stream", type=int, default=1, help="1: weight gradients on a side HIP stream (default, what train.py does); "
+                                                                "0: single stream (for per-kernel profiling)")
+    ap.add_argument("--windows", type=int, default=5, help="the timed region is repeated this many times (each = --steps steps, "
+                                                          "barrier + sync on both sides); the MEDIAN window is reported")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 (the reference's own arithmetic) step time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def build(args, device, rank, world):
-    from tests.golden import configs
-    from oracle.weights import synthetic_batch
+def dev_environment():
+    """Tamper evidence: the shipped library has no environment switches, but a development build (FS2_LIB_PATH -> -DFS2_DEV)
+    does (ablations that SKIP work).  The bench refuses to run with any of them set and records which library it loaded."""
+    bad = sorted(k for k in os.environ if k.startswith("FS2_") and k not in ("FS2_BENCH_BACKEND", "FS2_BENCH_SHARE_GPU"))
+    if bad:
+        print(f"bench.py: refusing to run with development variables set: {bad}", file=sys.stderr)
+        sys.exit(3)
+    from fastspeech2_amd import _lib
+    return os.path.relpath(_lib.LIB_PATH, ROOT)
+
+
+def build(args, device, rank, world, dtype=None):
+    from fastspeech2_amd import synthetic as configs
+    from fastspeech2_amd.synthetic import synthetic_batch
     from fastspeech2_amd.model import FastSpeech2, FastSpeech2Loss, ScheduledOptim
     from fastspeech2_amd import ddp
 
@@ -75,13 +91,14 @@ def build(args, device, rank, world):
         d = tempfile.mkdtemp(prefix="fs2_libritts_")
         _json.dump({f"spk{i}": i for i in range(2456)}, open(os.path.join(d, "speakers.json"), "w"))
         _json.dump(configs.LJ_STATS, open(os.path.join(d, "stats.json"), "w"))
-    pcfg, mcfg = configs.make(dec_layers=args.dec_layers, enc_layers=4, multi_speaker=libri, frame_level=args.frame_level)
+    pcfg, mcfg = configs.make_configs(dec_layers=args.dec_layers, enc_layers=4, multi_speaker=libri, frame_level=args.frame_level)
     if libri:
         pcfg["path"]["preprocessed_path"] = d
     torch.manual_seed(1234)
-    model = FastSpeech2(pcfg, mcfg, compute_dtype=args.dtype).to(device)
+    model = FastSpeech2(pcfg, mcfg, compute_dtype=dtype or args.dtype).to(device)
     model.train()
     model._ensure_flat(device)
+    model._engine.use_side_stream = bool(args.side_stream)
     if libri:
         # one length-bucketed batch out of a LibriTTS-like pool: log-normal phoneme counts (median 49, p95 ~176), the
         # pool is sorted and this rank takes the bucket at the 75th percentile (what BucketedBatchSampler deals per step)
@@ -132,12 +149,12 @@ def make_step(model, loss_fn, opt, b, exchange):
 
 def cpu_baseline(args):
     """CPU oracle (port of the reference algorithm) on a bounded sample: B=4, same L/T, fwd+loss+bwd+clip+Adam."""
-    from tests.golden import configs
+    from fastspeech2_amd import synthetic as configs
     from oracle import fs2_oracle as O
-    from oracle.weights import synthetic_batch
+    from fastspeech2_amd.synthetic import synthetic_batch
     from fastspeech2_amd.model import FastSpeech2
 
-    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
+    pcfg, mcfg = configs.make_configs(dec_layers=4, enc_layers=4)
     torch.manual_seed(1234)
     sd = {k: v.clone() for k, v in FastSpeech2(pcfg, mcfg).state_dict().items()}
     params = []
@@ -172,17 +189,18 @@ def synth_main(args):
     on LJSpeech-shaped synthetic text batches (random-init weights; duration-predictor bias set so that ~7 frames per
     phoneme are produced).  One process per GPU, replicas only (no collective)."""
     import math
-    from tests.golden import configs
-    from oracle.weights import synthetic_batch
+    from fastspeech2_amd import synthetic as configs
+    from fastspeech2_amd.synthetic import synthetic_batch
     from fastspeech2_amd.model import FastSpeech2
     from fastspeech2_amd import hifigan, utils
+    lib_used = dev_environment()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
     device = init_rank(world, local_rank)
-    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
+    pcfg, mcfg = configs.make_configs(dec_layers=4, enc_layers=4)
     torch.manual_seed(1234)
     model = FastSpeech2(pcfg, mcfg, compute_dtype=args.dtype)
     with torch.no_grad():
@@ -222,8 +240,36 @@ def synth_main(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt)
         tt[0] = tmax[0]
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented replay: HIP events around every conv_gemm launch of the acoustic model + vocoder (one stream)
+        from fastspeech2_amd import ops
+        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel", 5: "conv_gemm_p_kernel"}
+        ops.PROFILE = {}
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        by = {}
+        for (f, e0, e1, var, _hl, _S) in prof.get("conv_gemm", []):
+            d = by.setdefault(var, [0.0, 0.0, 0])
+            d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
+        if by:
+            dom = max(by, key=lambda v: by[v][1])
+            fl, ms, n = by[dom]
+            peak = MFMA_PEAK_TFLOPS[args.vocoder_dtype]
+            # the C = 32 / 64 residual-block convs (conv_skinny_kernel) are HBM-bound by construction (48-96 FLOP/B); every
+            # other variant is priced against the MFMA peak
+            roofline = {"bound": "mfma", "kernel": names.get(dom, str(dom)) + " (%s)" % args.vocoder_dtype, "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                        "launches_per_step": n // 2, "kernel_ms_per_step": round(ms / 2, 3), "avg_launch_us": round(ms / n * 1e3, 1),
+                        "gflop_per_launch": round(fl / n / 1e9, 2),
+                        "conv_gemm_family": {v2: {"kernel": names.get(v2, str(v2)), "launches_per_step": d[2] // 2, "ms_per_step": round(d[1] / 2, 3),
+                                                  "tflops": round(d[0] / (d[1] * 1e-3) / 1e12, 1)} for v2, d in sorted(by.items())}}
     if rank == 0:
         dt, audio_s, frames = tt.tolist()
+        if roofline is not None:
+            roofline["step_frac_of_peak"] = round(frames / dt * 614.1e6 / (MFMA_PEAK_TFLOPS[args.vocoder_dtype] * 1e12), 4)   # HiFi-GAN: 614.1 MFLOP per mel frame
         print(json.dumps({
             "metric": "batch-synth real-time factor (acoustic model + HiFi-GAN + int16, 22.05 kHz)", "value": round(dt / audio_s, 6),
             "unit": "s wall per s audio", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,8 +278,10 @@ def synth_main(args):
             "config": {"workload": f"BASELINE configs[4]: batch synthesis, {B} utterances/batch, L<={args.phonemes} phonemes, "
                                    f"~7 frames/phoneme, 4+4 FastSpeech2 + HiFi-GAN V1, PCM copied to host",
                        "audio_s_per_step": round(audio_s / args.steps, 2), "mel_frames_per_s": round(frames / dt, 1),
-                       "x_realtime": round(audio_s / dt, 1)}}))
+                       "x_realtime": round(audio_s / dt, 1), "library": lib_used, "dev_env": []},
+            "roofline": roofline}))
     if world > 1:
+        dist.barrier()                     # ranks leave together (rank 0 was still replaying for the roofline)
         dist.destroy_process_group()
 
 
@@ -282,6 +330,7 @@ def main():
         print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     import torch.distributed as dist
+    lib_used = dev_environment()
     device = init_rank(world, local_rank)
 
     from fastspeech2_amd import ddp, ops
@@ -328,16 +377,25 @@ def main():
 
     for _ in range(2):
         run_step()
+    # the timed region (EXACTLY --steps steps between barrier + synchronize on both sides) is repeated --windows times and the
+    # MEDIAN window is reported: one 20-step window is ~0.2 s, boxes differ by several per cent and clocks wander
+    window_s = []
+    for _ in range(max(1, args.windows)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        window_s.append(time.perf_counter() - t0)
+    wt = torch.tensor(window_s, device=device, dtype=torch.float64)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)              # per window: the slowest rank
+    window_s = sorted(wt.tolist())
+    dt = window_s[len(window_s) // 2]
     host_ms = None
     if args.host_time and graph is None:
         torch.cuda.synchronize()
@@ -346,14 +404,11 @@ def main():
             run_step()
         host_ms = (time.perf_counter() - h0) / 5 * 1e3        # time to ISSUE a step (the device is still running)
         torch.cuda.synchronize()
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     frames = b["mel_lens"].sum().to(torch.float64)
     padded = torch.tensor([float(args.batch * b["max_mel_len"])], device=device, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(frames)
         dist.all_reduce(padded)
-    dt = tmax.item()
     value = frames.item() * args.steps / dt
     final_loss = float((static_loss if graph is not None else loss).item())
 
@@ -378,21 +433,28 @@ def main():
         model._engine.use_side_stream = side
         rec = prof.get("conv_gemm", [])
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel"}
+        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel",
+                 5: "conv_gemm_p_kernel"}
+        # fraction of the padded rows that are valid, per sequence length (launches that pass `lens` skip fully padded tiles:
+        # `achieved` counts the reference's padded algorithmic FLOPs, `achieved_valid_rows` only those of valid rows)
+        vfrac = {int(b["max_mel_len"]): float(b["mel_lens"].sum()) / (args.batch * b["max_mel_len"]),
+                 int(b["max_src_len"]): float(b["src_lens"].sum()) / (args.batch * b["max_src_len"])}
         by = {}
-        for (f, e0, e1, var) in rec:
-            d = by.setdefault(var, [0.0, 0.0, 0])
+        for (f, e0, e1, var, has_lens, S_) in rec:
+            d = by.setdefault(var, [0.0, 0.0, 0, 0.0])
             d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
+            d[3] += f * (vfrac.get(int(S_), 1.0) if has_lens else 1.0)
         tot_ms = sum(d[1] for d in by.values())
         if tot_ms > 0:
             # the DOMINANT kernel = the conv_gemm variant with the largest share of the step (the 256x128 ring kernel: k=9 FFN
             # conv and k=5 PostNet conv, forward + data gradient); its rocprofv3 row is `conv_gemm_ring_kernel<...>`
             dom = max(by, key=lambda v: by[v][1])
-            fl, ms, n = by[dom]
+            fl, ms, n, flv = by[dom]
             ach = fl / (ms * 1e-3) / 1e12
             fam = sum(d[0] for d in by.values()) / (tot_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": names.get(dom, str(dom)) + " (%s)" % args.dtype,
                         "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "achieved_valid_rows": round(flv / (ms * 1e-3) / 1e12, 1), "frac_valid_rows": round(flv / (ms * 1e-3) / 1e12 / peak, 4),
                         "traffic": (pmc_traffic(names.get(dom, "conv_gemm")) if (args.dtype == "bf16" and args.workload == "ljspeech" and args.dec_layers == 4
                                                                                     and not args.frame_level and args.batch == 48) else None),   # PMC passes exist for the reported config only
                         "launches_per_step": n // 3, "kernel_ms_per_step": round(ms / 3, 3), "avg_launch_us": round(ms / n * 1e3, 1),
@@ -402,6 +464,21 @@ def main():
                                              for v2, d in sorted(by.items())},
                         "family_achieved": round(fam, 1), "family_frac": round(fam / peak, 4), "family_ms_per_step": round(tot_ms / 3, 3),
                         "step_frac_of_peak": round(value / world * train_flop_per_frame(args) / (peak * 1e12), 4)}
+    # secondary figure: the same step in fp32 compute (the reference's own arithmetic; exact-f32 MFMA, 157.3 TF roof)
+    fp32 = {}
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_fp32:
+        m32, l32, o32, b32, _, _ = build(args, device, rank, world, dtype="fp32")
+        s32, _ = make_step(m32, l32, o32, b32, None)
+        for _ in range(2):
+            s32()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            s32()
+        torch.cuda.synchronize()
+        t32 = (time.perf_counter() - t0) / 5
+        fp32 = {"fp32_ms_per_step": round(t32 * 1e3, 3), "fp32_frames_per_s": round(float(b32["mel_lens"].sum()) / t32, 1),
+                "fp32_frac_of_f32_peak": round(float(b32["mel_lens"].sum()) / t32 * train_flop_per_frame(args) / (MFMA_PEAK_TFLOPS["fp32"] * 1e12), 4)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only (host cores are shared by the ranks)
         cpu = cpu_baseline(args)
@@ -418,7 +495,9 @@ def main():
                                    "fwd+loss+bwd+clip+Adam, dropout on, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),
-                       "side_stream_wgrad": bool(model._engine.use_side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {})},
+                       "side_stream_wgrad": bool(model._engine.use_side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
+                       "windows": len(window_s), "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in window_s],
+                       "library": lib_used, "dev_env": [], **fp32},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -128,11 +128,12 @@ __device__ __forceinline__ float fs2_drop_scale(uint64_t seed, uint32_t idx, flo
     return (fs2_uniform(seed, idx) >= p) ? inv_keep : 0.0f;
 }
 
-// fs2_conv_gemm_last_variant() codes (mirrors include/fs2hip.h)
+// fs2_conv_gemm_variant() codes (mirrors include/fs2hip.h)
 #ifndef FS2_GEMM_PLAIN
 #define FS2_GEMM_PLAIN 1
 #define FS2_GEMM_DMA 2
 #define FS2_GEMM_RING 3
 #define FS2_GEMM_SKINNY 4
+#define FS2_GEMM_PERSIST 5
 #endif
 static inline int fs2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

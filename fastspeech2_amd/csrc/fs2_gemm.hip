@@ -22,72 +22,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct ConvGemmArgs {
-    const void* X; long ldx;
-    const void* W; long ldw;       // packed [N][taps*Cin]
-    const float* bias;             // [N] or null
-    const void* R; long ldr;       // residual added after activation, or null
-    void* Y; long ldy;
-    const int32_t* lens;           // per-sequence valid rows (rows t >= lens[b] are written as 0) or null
-    int M, N, Cin, S, taps, dil, pad;
-    int act; float slope;          // output activation
-    int in_act; float in_slope;    // activation applied to X on load (leaky-relu prologue of HiFi-GAN)
-    int accumulate; float out_scale;
-    int vec_ok;                    // Y / R rows are 16-byte addressable (ld % elems-per-16B == 0, aligned bases)
-    int dbg;                       // dev ablations (FS2_GEMM_DBG): 1 = loaders issue no DMA, 2 = consumers issue no MFMA
-};
-
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    switch (act) {
-        case FS2_ACT_RELU: return fmaxf(v, 0.f);
-        case FS2_ACT_TANH: return tanhf(v);
-        case FS2_ACT_LRELU: return v > 0.f ? v : v * slope;
-        default: return v;
-    }
-}
-
-// activation with the kind fixed at COMPILE time.  The epilogues run it on 64-128 accumulators per lane in fully unrolled
-// loops; with the run-time switch above every one of those elements carried its own scalar branch ladder plus an inlined
-// tanhf (the 256x128 kernel grew to ~17 k instructions, far beyond the instruction cache, and its epilogue cost ~8 us per
-// workgroup: r01i ablation 277 us with / 212 us without epilogue on the k=9 FFN conv).  Now the switch runs ONCE per
-// epilogue and selects a straight-line instantiation.
-template <int ACT> __device__ __forceinline__ float act_ct(float v, float slope) {
-    if (ACT == FS2_ACT_RELU) return fmaxf(v, 0.f);
-    if (ACT == FS2_ACT_TANH) return tanhf(v);
-    if (ACT == FS2_ACT_LRELU) return v > 0.f ? v : v * slope;
-    return v;                                            // none / gate (the gate is applied with the residual operand)
-}
-#define FS2_ACT_DISPATCH(act, CALL) do { switch (act) { \
-    case FS2_ACT_RELU: { constexpr int ACT = FS2_ACT_RELU; CALL; } break; \
-    case FS2_ACT_TANH: { constexpr int ACT = FS2_ACT_TANH; CALL; } break; \
-    case FS2_ACT_LRELU: { constexpr int ACT = FS2_ACT_LRELU; CALL; } break; \
-    default: { constexpr int ACT = FS2_ACT_NONE; CALL; } break; } } while (0)
-
-template <typename T> struct MmaTraits;
-template <> struct MmaTraits<float> { static constexpr int EPC = 4; };   // elements per 16-B chunk
-template <> struct MmaTraits<bf16_t> { static constexpr int EPC = 8; };
-
-__device__ __forceinline__ uint4 act_chunk_f32(uint4 v, float slope) {
-    float* f = reinterpret_cast<float*>(&v);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = f[i] > 0.f ? f[i] : f[i] * slope;
-    return v;
-}
-__device__ __forceinline__ uint4 act_chunk_bf16(uint4 v, float slope) {
-    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
-        lo = lo > 0.f ? lo : lo * slope;
-        hi = hi > 0.f ? hi : hi * slope;
-        u[i] = pack_bf16x2(lo, hi);
-    }
-    return v;
-}
+#include "fs2_gemm.h"
 
 // final stage of the epilogue (shared by both GEMM kernels): the f32 tile staged in LDS is written out in whole
 // 16-byte row segments; residual / ReLU-gate operand and the accumulate operand are read the same way.
@@ -567,12 +502,6 @@ __global__ void __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) conv_gemm_dma_kerne
 // Requires Cin % 64 == 0 and operand footprints < 2 GB (32-bit offsets); the host falls back to the 128^2 kernels
 // otherwise.  Rows outside [0, M) / [0, N) are CLAMPED instead of zero-filled: they only ever feed outputs that are
 // not stored, or taps that the boundary mask zeroes (tiles touching a sequence end always run the MASK variant).
-__device__ __forceinline__ void glds16_sbase(unsigned voff, const void* sbase, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
 
 template <bool ONE_TAP> struct RingCfg;
 template <> struct RingCfg<false> { static constexpr int D = 4, A_BYTES = 272 * 128, NA = 2, SCRATCH = 2 * 272 * 128, B_OFF = 2 * 272 * 128 + 1024, NJA = 9; };
@@ -609,7 +538,7 @@ __device__ __forceinline__ void ring_loader(const ConvGemmArgs& a, unsigned char
         int n = min(n0 + r, a.N - 1);
         offB[j] = (unsigned)n * (unsigned)(a.ldw * 2) + (unsigned)((lc ^ ((r >> 1) & 7)) << 4);
     }
-    const bool nodma = a.dbg & 1;
+    const bool nodma = FS2_DEV_DBG(a.dbg & 1);
     auto load_A = [&](int kc, int buf) {
         if (nodma) return;
         const unsigned char* base = Xb + (size_t)kc * 128;
@@ -806,7 +735,7 @@ __global__ void __launch_bounds__(768, 3) conv_gemm_ring_kernel(ConvGemmArgs a) 
             return;
         }
     }
-    if (a.dbg & 16) return;
+    if (FS2_DEV_DBG(a.dbg & 16)) return;
     f32x16 acc[2][2];
     if (wave >= 8) {
         ring_loader<ONE_TAP>(a, smem, m0, n0, lane, wave - 8);
@@ -828,7 +757,7 @@ __global__ void __launch_bounds__(768, 3) conv_gemm_ring_kernel(ConvGemmArgs a) 
         }
     }
     __syncthreads();                                       // every consumer is done reading the operand slots
-    if (a.dbg & 8) { if (tid == 0 && acc[0][0][0] == 12345.f) Y[0] = 0; return; }
+    if (FS2_DEV_DBG(a.dbg & 8)) { if (tid == 0 && acc[0][0][0] == 12345.f) Y[0] = 0; return; }
 
     // epilogue: the whole 256x128 f32 tile through LDS (128 KB), written by the consumers, stored by all 8 waves
     float* tile = reinterpret_cast<float*>(smem);
@@ -853,7 +782,7 @@ __global__ void __launch_bounds__(768, 3) conv_gemm_ring_kernel(ConvGemmArgs a) 
         FS2_ACT_DISPATCH(a.act, stage(std::integral_constant<int, ACT>{}));
     }
     __syncthreads();
-    if (a.dbg & 32) { if (tile[tid] == 12345.f) Y[0] = 0; return; }
+    if (FS2_DEV_DBG(a.dbg & 32)) { if (tile[tid] == 12345.f) Y[0] = 0; return; }
     if (tid < 512) {                                       // (the shared store path walks 128 x 16 chunks in whole strides of its thread count)
         gemm_store_tile<bf16_t, 128, 512>(a, tile, m0, n0, tid);
         gemm_store_tile<bf16_t, 128, 512>(a, tile + 128 * 128, m0 + 128, n0, tid);
@@ -1003,14 +932,71 @@ static void launch_skinny(const ConvGemmArgs& a, hipStream_t stream) {
     conv_skinny_kernel<C><<<(unsigned)fs2_cdiv(a.M, 128), 256, SkinnyCfg<C>::LDS, stream>>>(a);
 }
 
-// which kernel the calling thread's last fs2_conv_gemm dispatched to (measurement aid: lets bench.py attribute its
-// HIP-event durations to the same kernel names rocprofv3 reports)
-static thread_local int fs2_last_gemm_variant = 0;
-extern "C" int fs2_conv_gemm_last_variant(void) { return fs2_last_gemm_variant; }
+// defined in fs2_gemm_p.hip
+bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype);
+void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl);
+
+// Which kernel a launch description dispatches to: a PURE function of the description (no state, no environment in the
+// shipped build), shared by fs2_conv_gemm and by the query entry point fs2_conv_gemm_variant that bench.py uses to attribute
+// its HIP-event durations to the kernel names rocprofv3 reports.
+struct GemmPick { int variant; bool ring_inact, ks2; };
+static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map) {
+    const int M = a.M, N = a.N, Cin = a.Cin, taps = a.taps, dil = a.dil, in_act = a.in_act;
+    GemmPick p;
+    const long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
+    // taps == 1 keeps the register-staged kernel (its 3-stage pipeline wins when there is no halo to reuse)
+    const bool dma = in_act == FS2_ACT_NONE && taps > 1 && (taps - 1) * dil <= 16 && taps <= 32;
+    // ring-buffered 256x128 tiles once there are enough of them to fill the chip (FS2_GEMM_TILE=128|256: dev A/B only)
+    static const int force_tile = fs2_dev_env("FS2_GEMM_TILE", 0);
+    const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
+    p.ring_inact = in_act == FS2_ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f;
+    const bool ring_ok = dtype == FS2_BF16 && (in_act == FS2_ACT_NONE || p.ring_inact) && (taps == 1 || (taps >= 3 && (taps - 1) * dil <= 16 && taps <= 32)) &&
+                         Cin % 64 == 0 && (double)M * a.ldx * 2 < 2.0e9 && (double)N * taps * Cin * 2 < 2.0e9;
+    // taps == 1 contractions with a short K (4-12 steps) do not amortise the ring's fill: measured faster on the 128^2 kernel
+    bool big = ring_ok && big_tiles >= 170 && (taps > 1 || Cin >= 1024);
+    if (force_tile == 128) big = false;
+    if (force_tile == 256 && ring_ok) big = true;
+    // C = 128 stays on the 256x128 / 128^2 kernels: it is MFMA-bound there (k=11: 172 GFLOP per conv) and one tap per
+    // weight group leaves only 32 MFMAs per wave between barriers (r01j A/B: 13.1 ms with, 12.0 ms without bit 4|8)
+    static const int skinny_mask = fs2_dev_env("FS2_GEMM_SKINNY", 3);    // dev A/B bits
+    const int skinny_bit = Cin == 32 ? 1 : (Cin == 64 ? 2 : (in_act == FS2_ACT_NONE ? 4 : 8));
+    const bool skinny = (skinny_mask & skinny_bit) && dtype == FS2_BF16 && N == Cin && (Cin == 32 || Cin == 64 || Cin == 128) && taps <= 16 &&
+                        (taps - 1) * dil <= 64 && (in_act == FS2_ACT_NONE || in_act == FS2_ACT_LRELU) && a.vec_ok;
+    // persistent 256x128 kernel (fs2_gemm_p.hip): every shape the ring kernel takes plus the short-K one-tap contractions
+    // (its run-ahead loaders hide the per-tile ring fill those could not amortise).  FS2_GEMM_P=0: dev A/B against the ring.
+    static const int p_on = fs2_dev_env("FS2_GEMM_P", 1);
+    const bool persist = p_on && !skinny && fs2_conv_gemm_p_ok(a, has_map, dtype) && (taps > 1 || Cin >= 256);
+    // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
+    static const int ksplit_on = fs2_dev_env("FS2_GEMM_KSPLIT", 1);
+    p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= 32;
+    p.variant = skinny ? FS2_GEMM_SKINNY : (persist ? FS2_GEMM_PERSIST : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN)));
+    return p;
+}
+
+static void conv_gemm_fill(ConvGemmArgs& a, const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
+                           long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad, int act, float slope,
+                           int in_act, float in_slope, int accumulate, float out_scale, int dtype) {
+    const int epc = dtype == FS2_F32 ? 4 : 8;
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = (long)taps * Cin; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
+    a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps; a.dil = dil; a.pad = pad; a.act = act;
+    a.slope = slope; a.in_act = in_act; a.in_slope = in_slope; a.accumulate = accumulate; a.out_scale = out_scale;
+    a.dbg = 0;
+    a.vec_ok = (ldy % epc == 0) && (((uintptr_t)Y & 15) == 0) && (!R || ((ldr % epc == 0) && (((uintptr_t)R & 15) == 0)));
+}
+
+// stateless query: the FS2_GEMM_* code fs2_conv_gemm would dispatch this description to (aligned 16-byte-addressable
+// operands assumed, as every tensor the engine passes is).  has_lens / has_map: whether lens and tile_map are non-null.
+extern "C" int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens, int has_map, int M, int N, int Cin, int S, int taps,
+                                     int dil, int in_act, float in_slope, int dtype) {
+    ConvGemmArgs a;
+    conv_gemm_fill(a, nullptr, ldx, nullptr, nullptr, ldr ? (const void*)16 : nullptr, ldr, nullptr, ldy, has_lens ? (const int32_t*)16 : nullptr,
+                   M, N, Cin, S > 0 ? S : 1, taps, dil, 0, 0, 0.f, in_act, in_slope, 0, 1.f, dtype);
+    return conv_gemm_pick(a, dtype, has_map != 0).variant;
+}
 
 extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
-                             long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad,
-                             int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
+                             long ldy, const int32_t* lens, const int32_t* tile_map, int M, int N, int Cin, int S, int taps, int dil,
+                             int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
                              hipStream_t stream) {
     FS2_CHECK_ARG(X && W && Y, "conv_gemm: null pointer");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0 && dil > 0, "conv_gemm: bad shape M=%d N=%d Cin=%d S=%d taps=%d", M, N, Cin, S, taps);
@@ -1021,41 +1007,20 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     FS2_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0, "conv_gemm: X/W must be 16-byte aligned");
     if (M == 0) return FS2_OK;
     ConvGemmArgs a;
-    a.X = X; a.ldx = ldx; a.W = W; a.ldw = (long)taps * Cin; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
-    a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps; a.dil = dil; a.pad = pad; a.act = act;
-    a.slope = slope; a.in_act = in_act; a.in_slope = in_slope; a.accumulate = accumulate; a.out_scale = out_scale;
-    static const int gemm_dbg = [] { const char* e = getenv("FS2_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    conv_gemm_fill(a, X, ldx, W, bias, R, ldr, Y, ldy, lens, M, N, Cin, S, taps, dil, pad, act, slope, in_act, in_slope, accumulate, out_scale, dtype);
+    static const int gemm_dbg = fs2_dev_env("FS2_GEMM_DBG", 0);
     a.dbg = gemm_dbg;
-    a.vec_ok = (ldy % epc == 0) && (((uintptr_t)Y & 15) == 0) && (!R || ((ldr % epc == 0) && (((uintptr_t)R & 15) == 0)));
-    long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
-    // taps == 1 keeps the register-staged kernel (its 3-stage pipeline wins when there is no halo to reuse)
-    const bool dma = in_act == FS2_ACT_NONE && taps > 1 && (taps - 1) * dil <= 16 && taps <= 32;
-    // ring-buffered 256x128 tiles once there are enough of them to fill the chip; FS2_GEMM_TILE=128|256 forces a
-    // variant (dev A/B only)
-    static const int force_tile = [] { const char* e = getenv("FS2_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
-    const bool ring_inact = in_act == FS2_ACT_LRELU && in_slope > 0.f && in_slope < 1.f;
-    const bool ring_ok = dtype == FS2_BF16 && (in_act == FS2_ACT_NONE || ring_inact) && (taps == 1 || (taps >= 3 && (taps - 1) * dil <= 16 && taps <= 32)) &&
-                         Cin % 64 == 0 && (double)M * ldx * 2 < 2.0e9 && (double)N * taps * Cin * 2 < 2.0e9;
-    // taps == 1 contractions with a short K (4-12 steps) do not amortise the ring's fill: measured faster on the 128^2 kernel
-    bool big = ring_ok && big_tiles >= 170 && (taps > 1 || Cin >= 1024);
-    if (force_tile == 128) big = false;
-    if (force_tile == 256 && ring_ok) big = true;
-    // (r01i: a weight-stationary streaming kernel for the K = 256 one-tap contractions - W block resident in LDS, X tiles
-    // prefetched a tile ahead - measured within +-5 % of the 128^2 kernel: these launches are 20-60 us and already move
-    // 1.7-3.2 TB/s; what they lose is launch ramp and tail, not pipeline bubbles.  Removed again.)
-    // C = 128 stays on the 256x128 / 128^2 kernels: it is MFMA-bound there (k=11: 172 GFLOP per conv) and one tap per
-    // weight group leaves only 32 MFMAs per wave between barriers (r01j A/B: 13.1 ms with, 12.0 ms without bit 4|8)
-    static const int skinny_mask = [] { const char* e = getenv("FS2_GEMM_SKINNY"); return e ? atoi(e) : 3; }();    // dev A/B bits
-    const int skinny_bit = Cin == 32 ? 1 : (Cin == 64 ? 2 : (in_act == FS2_ACT_NONE ? 4 : 8));
-    const bool skinny = (skinny_mask & skinny_bit) && dtype == FS2_BF16 && N == Cin && (Cin == 32 || Cin == 64 || Cin == 128) && taps <= 16 &&
-                        (taps - 1) * dil <= 64 && (in_act == FS2_ACT_NONE || in_act == FS2_ACT_LRELU) && a.vec_ok;
-    fs2_last_gemm_variant = skinny ? FS2_GEMM_SKINNY : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN));
-    if (skinny) {
+    const GemmPick pk = conv_gemm_pick(a, dtype, tile_map != nullptr);
+    if (pk.variant == FS2_GEMM_SKINNY) {
         if (Cin == 32) launch_skinny<32>(a, stream);
         else if (Cin == 64) launch_skinny<64>(a, stream);
         else launch_skinny<128>(a, stream);
-    } else if (big) {
+    } else if (pk.variant == FS2_GEMM_PERSIST) {
+        static const int abl = fs2_dev_env("FS2_GEMM_ABL", 0);
+        fs2_conv_gemm_p_launch(a, tile_map, stream, abl);
+    } else if (pk.variant == FS2_GEMM_RING) {
         static Fs2DevOnce ring_once;
         const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
         const int dynk = RingCfg<false>::B_OFF + RingCfg<false>::D * RING_B_BYTES;
@@ -1065,12 +1030,12 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
             (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn1);
             (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dynk);
         });
-        if (ring_inact) {
+        if (pk.ring_inact) {
             if (taps == 1) conv_gemm_ring_kernel<true, true><<<(unsigned)big_tiles, 768, dyn1, stream>>>(a);
             else conv_gemm_ring_kernel<false, true><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
         } else if (taps == 1) conv_gemm_ring_kernel<true, false><<<(unsigned)big_tiles, 768, dyn1, stream>>>(a);
         else conv_gemm_ring_kernel<false, false><<<(unsigned)big_tiles, 768, dynk, stream>>>(a);
-    } else if (dma) {
+    } else if (pk.variant == FS2_GEMM_DMA) {
         const int dyn = 2 * 160 * 128 + 2 * 128 * 128;
         static Fs2DevOnce dma_once;
         dma_once.run([&] {
@@ -1078,12 +1043,8 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
             (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
             (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * dyn);
         });
-        // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
-        static const int ksplit_on = [] { const char* e = getenv("FS2_GEMM_KSPLIT"); return e ? atoi(e) : 1; }();
-        const int nkc64 = Cin / 64;
-        const bool ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * nkc64 >= 32;
         if (dtype == FS2_F32) conv_gemm_dma_kernel<float, 1><<<(unsigned)grid, 256, dyn, stream>>>(a);
-        else if (ks2) conv_gemm_dma_kernel<bf16_t, 2><<<(unsigned)grid, 512, 2 * dyn, stream>>>(a);
+        else if (pk.ks2) conv_gemm_dma_kernel<bf16_t, 2><<<(unsigned)grid, 512, 2 * dyn, stream>>>(a);
         else conv_gemm_dma_kernel<bf16_t, 1><<<(unsigned)grid, 256, dyn, stream>>>(a);
     } else if (dtype == FS2_F32) conv_gemm_kernel<float><<<(unsigned)grid, 256, 0, stream>>>(a);
     else conv_gemm_kernel<bf16_t><<<(unsigned)grid, 256, 0, stream>>>(a);
@@ -1474,7 +1435,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
     auto ktile = [&](auto bufc, int u) {
         constexpr int BUF = decltype(bufc)::value;
         constexpr int bufoff = BUF * (A_BYTES + X_BYTES);
-        const bool live = live_lds[BUF] && !(a.dbg & 2);
+        const bool live = live_lds[BUF] && !FS2_DEV_DBG(a.dbg & 2);
         if (live) read_frags(0, bufoff, 0);
         load_tile(std::integral_constant<int, BUF>{}, u + 2);
         if (live) {
@@ -1494,7 +1455,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
         ktile(I0{}, u);
         if (u + 1 < uend) ktile(I1{}, u + 1);
     }
-    if (a.dbg & 1) return;
+    if (FS2_DEV_DBG(a.dbg & 1)) return;
     const int fl = lane & 31, fh = lane >> 5;
     if (do_bias) {                                       // reduce the 16 row-threads of every column group through LDS
         float* red = reinterpret_cast<float*>(smem);     // [16][128]; the operand tiles are dead (last loop barrier passed)
@@ -1542,7 +1503,7 @@ template <int NT, int REM, int NW>
 static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream) {
     a.S = S_eff;
     a.g3 = g3;
-    static const int dbg = [] { const char* e = getenv("FS2_WGRAD_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = fs2_dev_env("FS2_WGRAD_DBG", 0);
     a.dbg = dbg;
     const int dyn = 2 * (64 * 256 + 72 * 256);
     static Fs2DevOnce once;
@@ -1555,8 +1516,8 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     // workgroup pays ~10 us of prologue/epilogue, so the depth is bounded from both sides (r01h sweep, tools/bench_wgrad.py):
     //   short reductions (encoder, 96 K-tiles)  -> ~192 workgroups;  1-tap GEMMs (2 workgroups per CU) -> ~384;  else ~768;
     //   and at least 8 (1-tap) / 16 (few-tile conv) K-tiles per workgroup when the reduction is long.
-    static const int wg_env = [] { const char* e = getenv("FS2_WGRAD_WGS"); return e ? atoi(e) : 0; }();
-    static const int ups_env = [] { const char* e = getenv("FS2_WGRAD_MINUPS"); return e ? atoi(e) : 0; }();
+    static const int wg_env = fs2_dev_env("FS2_WGRAD_WGS", 0);
+    static const int ups_env = fs2_dev_env("FS2_WGRAD_MINUPS", 0);
     // 8-wave tap-group kernels (one workgroup per CU): ONE round of <= 256 workgroups.  With two waves per SIMD a workgroup
     // no longer needs a successor queued behind it to hide its latencies, and every extra split is another full-tile burst
     // of atomics (r01k sweep: k=9 FFN 294 -> 250 us at 5 splits x 48 tiles, PostNet k=5 201 -> 158 us at 8 x 32).
@@ -1597,7 +1558,7 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     if (dtype == FS2_F32) conv_wgrad_kernel<float><<<grid, 256, 0, stream>>>(a);
     else if (dtype == FS2_BF16) {
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
-        static const int wg_waves = [] { const char* e = getenv("FS2_WGRAD_WAVES"); return e ? atoi(e) : 8; }();   // dev A/B: 4 | 8
+        static const int wg_waves = fs2_dev_env("FS2_WGRAD_WAVES", 8);   // dev A/B: 4 | 8
         if (fast && taps == 1) { launch_wgrad_bf16<1, 0, 4>(a, (lens && M % S == 0) ? S : M, 1, stream); bias_fused = true; }   // no taps, no lens: one "sequence" of M rows
         else if (fast && 2 * dil <= 8 && M % S == 0) {
             const int g3 = taps / 3, rem = taps - 3 * g3;

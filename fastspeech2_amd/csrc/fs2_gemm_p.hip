@@ -1,0 +1,541 @@
+// fs2_gemm_p.hip — PERSISTENT wave-specialised implicit-GEMM for the large bf16 contractions (gfx950).
+//
+// Same contraction family and LDS operand image as conv_gemm_ring_kernel (fs2_gemm.hip; reference call sites
+// transformer/SubLayers.py:39-41,54,87-88, transformer/Layers.py:129-137, model/modules.py:209-240), re-cut after the
+// round-1 measurements (profiles/r01k_pmc_mfma.md, VERDICT r01 "what's weak" 5):
+//   * 64x64 consumer wave tiles issue one ds_read_b128 per MFMA: 8 consumer waves ask the CU's LDS pipe for as many
+//     cycles as the four MFMA pipes have (co-bound by construction).  Here a consumer wave owns 64(M) x 128(N):
+//     6 fragment reads per 8 MFMAs, and there are only FOUR consumer waves (one per SIMD, 256 registers each) next to
+//     the four loader waves.  A lone consumer hides its reads by issuing exactly one ds_read_b128 behind each of the
+//     first six MFMAs of an 8-MFMA k-slice (<= 5 single-issue instructions fit under one 32-cycle MFMA) and waiting
+//     with a counted lgkmcnt - no read bursts.
+//   * the accumulators are kept TRANSPOSED (D[n][m] = W-fragment x X-fragment): a lane then owns one output row m and
+//     four runs of four consecutive columns; one v_permlane32_swap per register pair turns them into 16-byte runs, so
+//     the epilogue stores bf16 rows straight from registers - no f32 staging tile in LDS, no barriers, and the operand
+//     rings stay live, which is what makes the kernel PERSISTENT: one workgroup per CU walks a static list of tiles and
+//     its loader waves prefetch the next tile's operands while the consumers store the current one (round 1 paid ring
+//     fill + store burst per 256x128 tile: 86 us of a 304 us launch).
+//   * fully padded M-tiles (rows t >= lens[b]) are known before the launch (fs2_tile_map): the real tiles are dealt
+//     round-robin to the workgroups (M-fastest: neighbours share the weight slice), the padded ones are zero-filled by
+//     the consumer waves while the first operands are in flight.
+// Synchronisation: one raw s_barrier per K-step (64 deep) publishes the slot the loaders filled D-1 steps earlier and
+// releases the slot the consumers just left; LDS-DMA is issued from inline asm and tracked with counted vmcnt
+// (loaders), fragment reads with counted lgkmcnt (consumers) - see fs2_gemm.hip for why the compiler cannot do either.
+#include "fs2_gemm.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool ONE_TAP> struct PCfg;
+// conv (taps >= 3): activation halo tile (256 + 16 rows) double-buffered per Cin chunk, weight ring of D slots
+template <> struct PCfg<false> {
+    static constexpr int D = 5, A_BYTES = 272 * 128, SCRATCH = 2 * 272 * 128, B_OFF = 2 * 272 * 128 + 1024, NJA = 9;
+    static constexpr int AUX = B_OFF + D * 16384;
+};
+// taps == 1: activation and weight tiles both in rings of D slots
+template <> struct PCfg<true> {
+    static constexpr int D = 3, A_BYTES = 256 * 128, SCRATCH = 0, B_OFF = 3 * 256 * 128, NJA = 8;
+    static constexpr int AUX = B_OFF + D * 16384;
+};
+static constexpr int P_MAXB = 1024;                       // lens[] staged in LDS
+static constexpr int P_AUX_BYTES = P_MAXB * 4 + 4 * 512;  // lens + one 128-float bias line per consumer wave
+static constexpr int P_B_BYTES = 128 * 128;
+
+struct PSched {
+    int G, b;                  // workgroups in the launch, this workgroup
+    int ntm, ntn;              // M-tiles (real + padded), N-tiles
+    int n_real, n_pad;         // real / padded M-tiles (read from the tile map on the device)
+    const int32_t* tmap;       // [0] = n_real, [1 .. ntm] = real M-tiles then padded M-tiles; null = identity (no lens)
+};
+
+// k-th tile of this workgroup -> (M-tile, N-tile); the M-tile ids of a workgroup's first 64 tiles sit in `mt_list` (lane k)
+__device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_list, int& mt, int& nt) {
+    const int u = s.b + k * s.G;
+    nt = u / s.n_real;
+    const int mi = u - nt * s.n_real;
+    mt = s.tmap ? (int)__builtin_amdgcn_readlane(mt_list, k) : mi;
+}
+
+// ------------------------------------------------------------------------------------------------ loader waves
+template <bool ONE_TAP>
+__device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int lw,
+                                         unsigned mt_list, int ntiles) {
+    typedef PCfg<ONE_TAP> C;
+    constexpr int D = C::D, NJA = C::NJA;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(a.X);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(a.W);
+    const int nkc = a.Cin >> 6;
+    const int taps = ONE_TAP ? 1 : a.taps;
+    const int nsteps = taps * nkc;
+    const int total = ntiles * nsteps;                       // K-steps of this workgroup, all tiles
+    const int nchunks = ntiles * nkc;
+    const int lr = lane >> 3, lc = lane & 7;
+    const int arows = 256 + (taps - 1) * a.dil;
+    const unsigned smem_base = lds_addr(smem);
+
+    unsigned offA[NJA], ldsA[NJA], offB[4];
+    auto set_A = [&](int k) {
+        int mt, nt;
+        p_tile_of(sc, k, mt_list, mt, nt);
+        const int m0 = mt * 256;
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            const int wl = lw + 4 * j;
+            const bool live = wl * 8 < arows;               // wave-uniform
+            const int r = wl * 8 + lr;
+            const int g = min(max(m0 - a.pad + r, 0), a.M - 1);
+            offA[j] = live ? (unsigned)g * (unsigned)(a.ldx * 2) + (unsigned)((lc ^ ((r >> 1) & 7)) << 4) : 0u;
+            ldsA[j] = live ? (unsigned)(wl * 1024) : 0xffffffffu;
+        }
+    };
+    auto set_B = [&](int k) {
+        int mt, nt;
+        p_tile_of(sc, k, mt_list, mt, nt);
+        const int n0 = nt * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (lw * 4 + j) * 8 + lr;
+            const int n = min(n0 + r, a.N - 1);
+            offB[j] = (unsigned)n * (unsigned)(a.ldw * 2) + (unsigned)((lc ^ ((r >> 1) & 7)) << 4);
+        }
+    };
+    // ---- issue side: step being filled (D-1 ahead of the step being consumed); conv: chunk whose halo tile is fetched
+    int is = 0, ik = 0, ikc = 0, itap = 0, islot = 0;        // global step, its tile / chunk / tap / ring slot
+    int kA = -1, kB = -1;                                    // tiles the per-lane offsets are set for
+    auto issue_A = [&](int k, int kc, int buf_or_slot) {
+        if (k != kA) { set_A(k); kA = k; }
+        const unsigned char* base = Xb + (size_t)kc * 128;
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            const unsigned d = (ldsA[j] == 0xffffffffu) ? smem_base + C::SCRATCH : smem_base + buf_or_slot * C::A_BYTES + ldsA[j];
+            glds16_sbase(offA[j], base, __builtin_amdgcn_readfirstlane(d));
+        }
+    };
+    auto issue_step = [&]() {                                // operands of global step `is` -> slot `islot`
+        if (ik != kB) { set_B(ik); kB = ik; }
+        if (ONE_TAP) issue_A(ik, ikc, islot);
+        const unsigned char* base = Wb + ((size_t)itap * a.Cin + (size_t)ikc * 64) * 2;
+        const unsigned d0 = smem_base + C::B_OFF + islot * P_B_BYTES + lw * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_sbase(offB[j], base, d0 + j * 1024);
+    };
+    auto advance_issue = [&]() {
+        ++is;
+        if (++itap == taps) { itap = 0; if (++ikc == nkc) { ikc = 0; ++ik; } }
+        if (++islot == D) islot = 0;
+    };
+    if (!ONE_TAP) issue_A(0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) {
+        if (is < total) issue_step();
+        advance_issue();
+    }
+    // ---- consume side
+    int ck = 0, ckc = 0, ctap = 0, gc = 0;                   // tile / chunk / tap of the step being published; global chunk
+    for (int cs = 0; cs < total; ++cs) {
+        // my ops of step cs have landed = everything but the ops issued after them (compile-time counts per case)
+        if (total - 1 - cs < D - 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (ONE_TAP) {
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                      // (D-2) x (8 A + 4 B), D = 3
+        } else {
+            const bool a_young = (ctap >= 1 && ctap <= D - 2) && (gc + 1 < nchunks);   // halo tile of chunk gc+1 issued after B(cs)
+            if (a_young) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");         // (D-2) x 4 B + 9 A, D = 5
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                        // publishes slot(cs); the consumers have left slot(cs-1)
+        if (!ONE_TAP && ctap == 0 && gc + 1 < nchunks) {
+            int nk = ck, nkc_ = ckc + 1;
+            if (nkc_ == nkc) { nkc_ = 0; ++nk; }
+            issue_A(nk, nkc_, (gc + 1) & 1);
+        }
+        if (is < total) issue_step();
+        advance_issue();
+        if (++ctap == taps) { ctap = 0; ++gc; if (++ckc == nkc) { ckc = 0; ++ck; } }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ consumer waves
+#define FS2P_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define FS2P_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory")
+#define FS2P_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// epilogue straight from the transposed accumulators: lane (fl, fh) holds, for row m = mbase + fl, the columns
+// nb*32 + 8*g + 4*fh + e (g = r>>2, e = r&3).  v_permlane32_swap pairs (g, g+1) across the two half-waves so that a lane ends
+// up with columns nb*32 + fh*8 + [0,8) (from g = 0,1) and nb*32 + 16 + fh*8 + [0,8) (from g = 2,3): two 16-byte bf16 runs.
+template <int ACT>
+__device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][4], int m0, int n0, int wm, int fl, int fh,
+                                           const int32_t* lens_s, float* bias_s, int lane) {
+    bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
+    const bf16_t* R = reinterpret_cast<const bf16_t*>(a.R);
+    const bool gate = a.act == FS2_ACT_GATE;
+    // bias line of this tile -> this wave's private LDS line (same wave writes and reads: LDS ops are in order)
+    if (a.bias) {
+        if (lane < 32) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = n0 + lane * 4;
+            if (n + 4 <= a.N) bv = *reinterpret_cast<const float4*>(a.bias + n);
+            else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (n + e < a.N) t[e] = a.bias[n + e]; bv = make_float4(t[0], t[1], t[2], t[3]); }
+            *reinterpret_cast<float4*>(bias_s + lane * 4) = bv;
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + wm * 64 + mb * 32 + fl;
+        const bool rowok = m < a.M;
+        bool padrow = false;
+        if (a.lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
+        bf16_t* yrow = Y + (size_t)m * a.ldy;
+        const bf16_t* rrow = R ? R + (size_t)m * a.ldr : nullptr;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            float c[2][8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][e]), __float_as_uint(acc[mb][nb][4 + e]), false, false);
+                u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][8 + e]), __float_as_uint(acc[mb][nb][12 + e]), false, false);
+                c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
+                c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int nl = nb * 32 + ch * 16 + fh * 8;
+                const int n = n0 + nl;
+                if (!rowok || n >= a.N) continue;            // N % 8 == 0: a chunk is inside or outside
+                float v[8];
+                if (a.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias_s + nl), b1 = *reinterpret_cast<const float4*>(bias_s + nl + 4);
+                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(c[ch][e] + bb[e], a.slope);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(c[ch][e], a.slope);
+                }
+                if (rrow) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(rrow + n);
+                    const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+                        v[2 * e] = gate ? (r0 > 0.f ? v[2 * e] : 0.f) : v[2 * e] + r0;
+                        v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] *= a.out_scale; if (padrow) v[e] = 0.f; }
+                if (a.accumulate) {
+                    const uint4 yy = *reinterpret_cast<const uint4*>(yrow + n);
+                    const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+                }
+                uint4 o;
+                uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<uint4*>(yrow + n) = o;
+            }
+        }
+    }
+}
+
+// ABL (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue
+template <bool ONE_TAP, int ABL>
+__device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int wm,
+                                           unsigned mt_list, int ntiles, const int32_t* lens_s, float* bias_s) {
+    typedef PCfg<ONE_TAP> C;
+    constexpr int D = C::D;
+    const int nkc = a.Cin >> 6;
+    const int taps = ONE_TAP ? 1 : a.taps;
+    const int nsteps = taps * nkc;
+    const int total = ntiles * nsteps;
+    const int fl = lane & 31, fh = lane >> 5;
+    const unsigned smem_u = lds_addr(smem);
+    // fragment addresses.  Lane (fl, fh) reads 16-byte chunk c = fh*4 + j of its row in k-slice j; chunks are XOR-swizzled
+    // with the key ((physical row >> 1) & 7), and (c0 | j) ^ key == (c0 ^ key) ^ j because c0 = fh*4 has its low bits clear:
+    // one per-lane constant per operand and step, the k-slice enters as an immediate XOR.
+    const unsigned c0 = (unsigned)(fh * 4);
+    const unsigned ckb = c0 ^ (unsigned)((fl >> 1) & 7);                     // weight rows are never shifted
+    const unsigned blane = smem_u + C::B_OFF + (unsigned)(fl * 128);
+    const unsigned alane = smem_u + (unsigned)((wm * 64 + fl) * 128);
+    auto a_base = [&](int abuf, int tap) -> unsigned { return alane + (unsigned)(abuf * C::A_BYTES + tap * a.dil * 128); };
+    auto a_key = [&](int tap) -> unsigned { return c0 ^ (unsigned)(((fl + tap * a.dil) >> 1) & 7); };   // key of the PHYSICAL halo row
+    auto b_base = [&](int slot) -> unsigned { return blane + (unsigned)(slot * P_B_BYTES); };
+
+    u32x4 Af[2][2], Bf[2][4];                                // [set][mb], [set][nb]: fragment double buffer
+    f32x16 acc[2][4];
+
+    // one k-slice: 8 MFMAs of fragment set SET, the six reads of the NEXT slice (k-slice JN of the step whose operands sit at
+    // ABASE / AKEY / BBASE, into set SET^1) issued one behind each of the first six MFMAs.
+    // Read order A0 B0 B1 B2 B3 A1 / MFMA order (B0,A0) (B1,A0) (B2,A0) (B3,A0) (B0,A1) ... : the operand an MFMA needs was
+    // issued >= 4 MFMA slots earlier and "at most 4 younger LDS reads outstanding" is the same count at every position
+    // (lgkmcnt counts LDS operations in order).
+#define FS2P_MFMA(SET, MB, NB, AV)                                                                                          \
+    if (!(ABL & 1)) acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bf[SET][NB]),        \
+                                                                       __builtin_bit_cast(bf16x8, AV), acc[MB][NB], 0, 0, 0)
+#define FS2P_SLICE(SET, MASKED, LIVE0, LIVE1, DO_READS, JN, ABASE, AKEY, BBASE)                                             \
+    do {                                                                                                                    \
+        u32x4 av0, av1;                                                                                                     \
+        FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
+        av0 = Af[SET][0]; if (MASKED && !(LIVE0)) av0 = u32x4{0u, 0u, 0u, 0u};                                              \
+        FS2P_MFMA(SET, 0, 0, av0); FS2P_FENCE();                                                                            \
+        const unsigned aa_ = (ABASE) + ((((AKEY)) ^ (unsigned)(JN)) << 4);                                                  \
+        const unsigned ba_ = (BBASE) + ((ckb ^ (unsigned)(JN)) << 4);                                                       \
+        if (DO_READS) { FS2P_DS_READ(Af[SET ^ 1][0], aa_, 0); } FS2P_FENCE();                                               \
+        FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
+        FS2P_MFMA(SET, 0, 1, av0); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][0], ba_, 0); } FS2P_FENCE();                                               \
+        FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
+        FS2P_MFMA(SET, 0, 2, av0); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][1], ba_, 4096); } FS2P_FENCE();                                            \
+        FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
+        FS2P_MFMA(SET, 0, 3, av0); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][2], ba_, 8192); } FS2P_FENCE();                                            \
+        FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
+        av1 = Af[SET][1]; if (MASKED && !(LIVE1)) av1 = u32x4{0u, 0u, 0u, 0u};                                              \
+        FS2P_MFMA(SET, 1, 0, av1); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][3], ba_, 12288); } FS2P_FENCE();                                           \
+        FS2P_MFMA(SET, 1, 1, av1); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Af[SET ^ 1][1], aa_, 4096); } FS2P_FENCE();                                            \
+        FS2P_MFMA(SET, 1, 2, av1); FS2P_FENCE();                                                                            \
+        FS2P_MFMA(SET, 1, 3, av1); FS2P_FENCE();                                                                            \
+    } while (0)
+
+    int gs = 0, gc = 0, slot = 0;                            // global step / chunk, ring slot of step gs
+    FS2P_WAIT_LGKM(0);                                       // kernel arguments, lens staging: lgkmcnt is ours from here
+    __builtin_amdgcn_s_barrier();                            // slot(0) published
+    if (!(ABL & 2)) {
+        const unsigned aa = a_base(0, 0) + (a_key(0) << 4), ba = b_base(0) + (ckb << 4);
+        FS2P_DS_READ(Af[0][0], aa, 0); FS2P_DS_READ(Bf[0][0], ba, 0); FS2P_DS_READ(Bf[0][1], ba, 4096);
+        FS2P_DS_READ(Bf[0][2], ba, 8192); FS2P_DS_READ(Bf[0][3], ba, 12288); FS2P_DS_READ(Af[0][1], aa, 4096);
+        // these six sit outside the tile loop: have them LANDED before the compiler may copy their registers into the
+        // loop-carried ones (a copy of a register with a read in flight would carry stale data)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
+    }
+    for (int k = 0; k < ntiles; ++k) {
+        int mt, nt;
+        p_tile_of(sc, k, mt_list, mt, nt);
+        const int m0 = mt * 256, n0 = nt * 128;
+        // tap-validity bits of this lane's two rows (bit j: tap j stays inside the row's own sequence)
+        unsigned vmask[2] = {0xffffffffu, 0xffffffffu};
+        bool need_mask = false;
+        if (!ONE_TAP) {
+            const unsigned full = (taps >= 32) ? 0xffffffffu : ((1u << taps) - 1u);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int m = m0 + wm * 64 + mb * 32 + fl;
+                unsigned msk = 0;
+                if (m < a.M) {
+                    const int t = m % a.S;
+                    for (int j = 0; j < taps; ++j) {
+                        const int ts = t + j * a.dil - a.pad;
+                        if (ts >= 0 && ts < a.S) msk |= 1u << j;
+                    }
+                }
+                vmask[mb] = msk;
+                need_mask = need_mask || (msk != full);
+            }
+            need_mask = __builtin_amdgcn_ballot_w64(need_mask) != 0ull;      // wave-uniform
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        auto run_tile = [&](auto maskc) {
+            constexpr bool MASKED = decltype(maskc)::value;
+            for (int kc = 0; kc < nkc; ++kc) {
+                for (int tap = 0; tap < taps; ++tap) {
+                    const int abuf = ONE_TAP ? slot : (gc & 1);
+                    const bool live0 = (vmask[0] >> tap) & 1u, live1 = (vmask[1] >> tap) & 1u;
+                    const bool more = gs + 1 < total;                       // another step follows (this tile or the next)
+                    const unsigned ab = a_base(abuf, tap), ak = a_key(tap), bb = b_base(slot);
+                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 1, ab, ak, bb);
+                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 2, ab, ak, bb);
+                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 3, ab, ak, bb);
+                    FS2P_WAIT_LGKM(0); FS2P_FENCE();                        // every read of slot(gs) / its halo tile has landed
+                    if (more) __builtin_amdgcn_s_barrier();                 // slot(gs+1) published, slot(gs) released
+                    FS2P_FENCE();
+                    int nslot = slot + 1; if (nslot == D) nslot = 0;
+                    int ntap = tap + 1, ngc = gc; if (ntap == taps) { ntap = 0; ++ngc; }
+                    const int nabuf = ONE_TAP ? nslot : (ngc & 1);
+                    const unsigned nab = a_base(nabuf, ntap), nak = a_key(ntap), nbb = b_base(nslot);
+                    // (after the workgroup's very last step these six reads fetch operands nobody uses: issuing them unconditionally keeps the
+                    // fragment registers single-definition - a conditional read would make the compiler merge two register sets with
+                    // copies, and a copy of a register with a read in flight carries stale data)
+                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 0, nab, nak, nbb);
+                    ++gs; slot = nslot; gc = ngc;
+                }
+            }
+        };
+        if (need_mask) run_tile(std::true_type{}); else run_tile(std::false_type{});
+        if (k + 1 == ntiles) FS2P_WAIT_LGKM(0);               // the dangling prefetch of the last step
+
+        if (!(ABL & 4)) {
+            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wm, fl, fh, lens_s, bias_s, lane)));
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s += acc[i][j][0];
+            if (s == 12345.678f) reinterpret_cast<bf16_t*>(a.Y)[0] = 0;
+        }
+        if (ABL & 2) asm volatile("" :: "v"(Af[0][0]), "v"(Bf[0][0]));
+    }
+#undef FS2P_SLICE
+#undef FS2P_MFMA
+}
+
+template <bool ONE_TAP, int ABL>
+__global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSched sc0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef PCfg<ONE_TAP> C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PSched sc = sc0;
+    sc.b = blockIdx.x;
+    if (sc.tmap) {                                           // the real-tile count lives on the device (no host sync anywhere)
+        sc.n_real = __builtin_amdgcn_readfirstlane(sc.tmap[0]);
+        sc.n_pad = sc.ntm - sc.n_real;
+    }
+    int32_t* lens_s = reinterpret_cast<int32_t*>(smem + C::AUX);
+    float* bias_s = reinterpret_cast<float*>(smem + C::AUX + P_MAXB * 4) + (wave & 3) * 128;
+    const int n_units = sc.n_real * sc.ntn;
+    const int ntiles = (n_units - sc.b + sc.G - 1) / sc.G;   // 0 when every real tile went to lower-numbered workgroups
+    // M-tile ids of this workgroup's tiles (<= 64 per workgroup: guaranteed by the launcher when a tile map is used);
+    // loaded separately in the two roles so that the consumers' register pressure cannot spill the loaders' copy
+    auto load_mt_list = [&]() -> unsigned {
+        unsigned v = 0;
+        if (sc.tmap) {
+            const int u = sc.b + lane * sc.G;
+            if (u < n_units) v = (unsigned)sc.tmap[1 + u % sc.n_real];          // (n_units > 0 implies n_real > 0)
+        }
+        return v;
+    };
+    if (wave < 4) {
+        // per-sequence lengths -> LDS (the epilogue's padded-row test must not wait on global memory behind its own stores)
+        if (a.lens) {
+            const int B = a.M / a.S;
+            for (int i = tid; i < B; i += 256) lens_s[i] = a.lens[i];
+        }
+        // fully padded tiles of this workgroup: zeros (while the loaders fill the rings)
+        if (!a.accumulate && sc.n_pad > 0) {
+            bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
+            const int n_pu = sc.n_pad * sc.ntn;
+            for (int p = sc.b; p < n_pu; p += sc.G) {
+                const int nt = p / sc.n_pad, pi = p - nt * sc.n_pad;
+                const int m0 = sc.tmap[1 + sc.n_real + pi] * 256, n0 = nt * 128;
+                for (int i = tid; i < 256 * 16; i += 256) {
+                    const int m = m0 + (i >> 4), n = n0 + (i & 15) * 8;
+                    if (m < a.M && n < a.N) *reinterpret_cast<uint4*>(Y + (size_t)m * a.ldy + n) = make_uint4(0, 0, 0, 0);
+                }
+            }
+        }
+        // the four consumer waves make the staged lengths visible to each other before anyone's epilogue: they all pass
+        // the per-step barriers (>= 1) before the first epilogue, and LDS writes are ordered ahead of the wave's barrier
+        // arrival by the s_waitcnt lgkmcnt(0) in front of the first barrier.
+        if (ntiles > 0) p_consumer<ONE_TAP, ABL>(a, sc, smem, lane, wave, load_mt_list(), ntiles, lens_s, bias_s);
+    } else if (ntiles > 0) {                                 // (a workgroup without real tiles runs no barrier on either side)
+        p_loader<ONE_TAP>(a, sc, smem, lane, wave - 4, load_mt_list(), ntiles);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ tile map
+// out[0] = number of REAL 256-row M-tiles, out[1 ..] = their indices (ascending), then the fully padded ones.  A tile is
+// padded when all of its rows belong to ONE sequence's tail t >= lens[b] (the same rule the other GEMM kernels apply).
+__global__ void __launch_bounds__(64) tile_map_kernel(const int32_t* __restrict__ lens, int M, int S, int rows, int32_t* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const int ntm = (M + rows - 1) / rows;
+    int n_real = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int n = 0;
+        for (int base = 0; base < ntm; base += 64) {
+            const int tm = base + lane;
+            bool real = false, valid = tm < ntm;
+            if (valid) {
+                const int m0 = tm * rows, mlast = min(m0 + rows - 1, M - 1);
+                const int b0 = m0 / S, b1 = mlast / S;
+                real = !(b0 == b1 && (m0 - b0 * S) >= lens[b0]);
+            }
+            const bool pick = valid && (pass == 0 ? real : !real);
+            const unsigned long long msk = __builtin_amdgcn_ballot_w64(pick);
+            const int pos = n + __builtin_popcountll(msk & ((1ull << lane) - 1ull));
+            if (pick) out[1 + (pass == 0 ? 0 : n_real) + pos] = tm;
+            n += __builtin_popcountll(msk);
+        }
+        if (pass == 0) { n_real = n; if (lane == 0) out[0] = n; }
+    }
+}
+
+extern "C" int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, hipStream_t stream) {
+    FS2_CHECK_ARG(lens && out && B > 0 && S > 0 && rows > 0, "tile_map: bad arguments");
+    tile_map_kernel<<<1, 64, 0, stream>>>(lens, B * S, S, rows, out);
+    FS2_CHECK_LAUNCH("tile_map");
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+static int fs2_cu_count() {
+    static int cus[64] = {0};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (!cus[d]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+        cus[d] = n;
+    }
+    return cus[d];
+}
+
+template <bool ONE_TAP, int ABL>
+static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream) {
+    constexpr int dyn = PCfg<ONE_TAP>::AUX + P_AUX_BYTES;
+    static Fs2DevOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_p_kernel<ONE_TAP, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
+    conv_gemm_p_kernel<ONE_TAP, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
+}
+
+// Eligibility of the persistent kernel (pure function of the launch description; shared with fs2_conv_gemm_variant).
+bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype) {
+    if (dtype != FS2_BF16 || a.in_act != FS2_ACT_NONE) return false;
+    const int taps = a.taps;
+    if (!(taps == 1 || (taps >= 3 && (taps - 1) * a.dil <= 16 && taps <= 32))) return false;
+    if (a.Cin % 64 != 0 || !a.vec_ok || a.N % 8 != 0) return false;
+    if ((double)a.M * a.ldx * 2 >= 2.0e9 || (double)a.N * taps * a.Cin * 2 >= 2.0e9) return false;
+    const long tiles = (long)fs2_cdiv(a.M, 256) * fs2_cdiv(a.N, 128);
+    if (a.lens && (!has_map || a.M / a.S > P_MAXB)) return false;
+    const int cus = fs2_cu_count();
+    if (tiles < cus / 2) return false;                       // too few tiles to fill the chip: the 128^2 kernels do better
+    const long G = tiles < cus ? tiles : cus;
+    if (a.lens && (tiles + G - 1) / G > 64) return false;    // a workgroup's M-tile ids travel in one VGPR (lane k = k-th tile)
+    return true;
+}
+
+// The real-tile count lives in tile_map[0] on the device; the launch geometry must not depend on it (no host sync), so
+// G = min(CUs, all tiles) and workgroups that find no real tile only zero-fill their share of the padded ones.
+void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl) {
+    const int ntm = fs2_cdiv(a.M, 256), ntn = fs2_cdiv(a.N, 128);
+    const int cus = fs2_cu_count();
+    PSched sc;
+    sc.tmap = a.lens ? tile_map : nullptr;
+    sc.ntm = ntm; sc.ntn = ntn; sc.b = 0;
+    sc.n_real = ntm; sc.n_pad = 0;
+    sc.G = (int)((long)ntm * ntn < cus ? (long)ntm * ntn : cus);
+    const int taps = a.taps;
+    (void)abl;
+#ifdef FS2_DEV
+    switch (abl) {
+        case 1: if (taps == 1) launch_p<true, 1>(a, sc, stream); else launch_p<false, 1>(a, sc, stream); return;
+        case 2: if (taps == 1) launch_p<true, 2>(a, sc, stream); else launch_p<false, 2>(a, sc, stream); return;
+        case 3: if (taps == 1) launch_p<true, 3>(a, sc, stream); else launch_p<false, 3>(a, sc, stream); return;
+        case 4: if (taps == 1) launch_p<true, 4>(a, sc, stream); else launch_p<false, 4>(a, sc, stream); return;
+        default: break;
+    }
+#endif
+    if (taps == 1) launch_p<true, 0>(a, sc, stream); else launch_p<false, 0>(a, sc, stream);
+}

@@ -46,13 +46,12 @@ class Engine:
         self.Bf = dict(model.named_buffers())
         self.G = None   # name -> grad view (built lazily)
         self.grad_hook = None   # callable(end_offset, producer_streams): flat_grad[0:end_offset) is final (see ddp.GradExchange.ready)
-        import os
-        self.use_side_stream = os.environ.get("FS2_SIDE_STREAM", "1") != "0"
-        self._skip_wgrad = os.environ.get("FS2_SKIP_WGRAD", "0") == "1"
+        self.use_side_stream = True     # weight gradients on a side HIP stream (set False for single-stream profiling: bench.py --side-stream 0)
         self._side_stream = None
         self._side = None
         self._side_keep = []
         self._pack_pending = False
+        self._tmaps = {}
 
     # ------------------------------------------------------------------ weights
     def _flat_view(self, first_name, numel, shape, grad=False):
@@ -191,22 +190,24 @@ class Engine:
             self.grad_hook(end, (self._side,) if self._side is not None else ())
 
     # ------------------------------------------------------------------ building blocks
+    def _tmap(self, lens):
+        """tile map of a lengths tensor this forward registered (None otherwise: the non-persistent kernels run)."""
+        return self._tmaps.get(lens.data_ptr()) if lens is not None else None
+
     def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
         wf, _, b, shape = W[key]
-        return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res)
+        return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res, tmap=self._tmap(lens))
 
     def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None, lens=None):
         """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
         _, wd, _, shape = W[key]
-        return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens)
+        return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens, tmap=self._tmap(lens))
 
     def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0, lens=None):
         """weight (+ bias) gradient of one contraction.  Weight gradients are OFF the critical path of backward (nothing
         downstream reads them until the optimiser), so they are issued on a side HIP stream: they fill the CUs that the
         data-gradient chain's kernels leave idle in their last partial round of workgroups (e.g. the k=9 data gradient runs
         348 one-per-CU workgroups = 1.36 rounds) and overlap the chain's small latency-bound launches."""
-        if self._skip_wgrad:                    # dev ablation (FS2_SKIP_WGRAD=1): how long is the critical chain alone?
-            return
         if gw.dim() == 3:
             gw = gw.permute(0, 2, 1)            # tap-major storage of the gradient
         side = self._side
@@ -364,6 +365,7 @@ class Engine:
         p_vp = self.vp["dropout"] if drop else 0.0
         p_pn = 0.5 if drop else 0.0
         src_lens32 = st.src_lens.to(torch.int32)
+        self._tmaps = {src_lens32.data_ptr(): ops.tile_map(src_lens32, B, L)}
 
         # ---- encoder (transformer/Models.py:73-100)
         n_head = self.tc["encoder_head"]
@@ -413,6 +415,7 @@ class Engine:
         cum, idx, mel_len = ops.lr_index(dur, Tdec)
         st.mel_lens_out, st.Tdec = mel_len, Tdec
         dec_lens32 = torch.clamp(mel_len, max=Tdec).to(torch.int32)
+        self._tmaps[dec_lens32.data_ptr()] = ops.tile_map(dec_lens32, B, Tdec)
         frame_level = (not pitch_phone) or (not energy_phone)
         pe_dec = self._pe(P["decoder.position_enc"], Tdec)
         sv.x_lr_in = None
@@ -477,6 +480,7 @@ class Engine:
             sv.dec_out, sv.texts, sv.speakers = y, st.texts, st.speakers
             sv.pitch_phone, sv.energy_phone = pitch_phone, energy_phone
             sv.p_pn = p_pn
+            sv.tmaps = self._tmaps
         return (mel_o, post_o, p_pred, e_pred, logd), sv
 
     # ------------------------------------------------------------------ whole-model backward
@@ -491,6 +495,7 @@ class Engine:
             m._flat_grad.zero_()
             m.attach_grads()
         W, B, L, T, seed_dev = sv.W, sv.B, sv.L, sv.T, sv.seed_dev
+        self._tmaps = sv.tmaps
         n_mel = P["mel_linear.weight"].shape[0]
         self._side_begin()
 

@@ -91,8 +91,9 @@ def pack_weight(w, dtype, want_fwd=True, want_dgrad=True, wf=None, wd=None):
 # ------------------------------------------------------------------ contraction
 def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0, lens=None, res=None, out=None,
               in_act=ACT_NONE, in_slope=0.0, accumulate=False, out_scale=1.0, ldx=None, M=None, Cin=None, N=None,
-              ldy=None):
-    """x: [M, Cin] rows (or any buffer with row stride ldx); wpacked: [N, taps, Cin]; returns [M, N]."""
+              ldy=None, tmap=None):
+    """x: [M, Cin] rows (or any buffer with row stride ldx); wpacked: [N, taps, Cin]; returns [M, N].
+    tmap: tile_map(lens, B, S) of the same lens (optional; lets the persistent kernel skip fully padded M-tiles)."""
     if M is None:
         M = x.shape[0]
     if Cin is None:
@@ -109,11 +110,24 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("fs2_conv_gemm", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), M, N, Cin, S,
+    _lib.call("fs2_conv_gemm", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), M, N, Cin, S,
               taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
     if PROFILE is not None:
         e1.record()
-        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, _lib.load().fs2_conv_gemm_last_variant()))
+        var = _lib.load().fs2_conv_gemm_variant(ldx, ldy, ldr, int(lens is not None), int(tmap is not None), M, N, Cin, S, taps, dil,
+                                                in_act, in_slope, dt(x))
+        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, var, lens is not None, S))
+    return out
+
+
+TILE_ROWS = 256      # M-tile height of the persistent contraction kernel (fs2_gemm_p.hip)
+
+
+def tile_map(lens, B, S):
+    """[n_real, real 256-row M-tiles ..., fully padded M-tiles ...] of the [B*S] row space (device int32); see fs2_tile_map."""
+    ntm = (B * S + TILE_ROWS - 1) // TILE_ROWS
+    out = torch.empty(1 + ntm, device=lens.device, dtype=torch.int32)
+    _lib.call("fs2_tile_map", _p(lens), B, S, TILE_ROWS, _p(out), _stream())
     return out
 
 

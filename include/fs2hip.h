@@ -42,15 +42,25 @@ const char* fs2_last_error(void);
  *   model/modules.py:209-240,291-296 (VariancePredictor Conv k=3); model/fastspeech2.py:95 (mel_linear);
  *   transformer/Layers.py:129-137 (PostNet k=5); hifigan/models.py:96-103,150-163; audio/stft.py:66-72. */
 int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Y,
-                  long ldy, const int32_t* lens, int M, int N, int Cin, int S, int taps, int dil, int pad, int act,
-                  float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
+                  long ldy, const int32_t* lens, const int32_t* tile_map, int M, int N, int Cin, int S, int taps, int dil,
+                  int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
                   fs2_stream_t stream);
-/* Kernel the calling thread's last fs2_conv_gemm dispatched to (thread-local; a measurement aid for bench.py). */
+/* tile_map (optional, from fs2_tile_map with rows = 256 for the same lens / S / M): lets the persistent kernel deal only
+ * the M-tiles that hold valid rows to its workgroups.  With lens != NULL and tile_map == NULL the non-persistent kernels
+ * run (same results).
+ * fs2_tile_map: out[0] = number of REAL `rows`-row M-tiles of the [B*S] row space, out[1..] = their indices (ascending)
+ * followed by the fully padded ones (all rows in one sequence's tail t >= lens[b]); out holds 1 + ceil(B*S/rows) ints. */
+int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, fs2_stream_t stream);
+/* Which kernel fs2_conv_gemm dispatches a launch description to: a pure function (no state) - a measurement aid that
+ * lets bench.py attribute HIP-event durations to the kernel names rocprofv3 reports.  has_lens / has_map: whether
+ * lens / tile_map would be non-NULL; ldr = 0 without a residual operand. */
 #define FS2_GEMM_PLAIN 1   /* conv_gemm_kernel: 128x128 register-staged */
 #define FS2_GEMM_DMA 2     /* conv_gemm_dma_kernel: 128x128 LDS-DMA, halo reuse (incl. in-workgroup split-K) */
 #define FS2_GEMM_RING 3    /* conv_gemm_ring_kernel: 256x128 wave-specialised */
 #define FS2_GEMM_SKINNY 4  /* conv_skinny_kernel: C = 32 / 64 */
-int fs2_conv_gemm_last_variant(void);
+#define FS2_GEMM_PERSIST 5 /* conv_gemm_p_kernel: persistent 256x128, 64x128 consumer wave tiles, register epilogue */
+int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens, int has_map, int M, int N, int Cin, int S, int taps,
+                          int dil, int in_act, float in_slope, int dtype);
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
  * -> Wf[n][j][c] (forward: dtype cast) and/or Wd[c][j][n] = W[n][k-1-j][c] (data gradient: tap flip + transpose). */
 int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, fs2_stream_t stream);

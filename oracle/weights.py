@@ -44,31 +44,4 @@ def seeded_state_dict(template_sd, seed, keep=("position_enc", "pitch_bins", "en
     return out
 
 
-def synthetic_batch(seed, B, L, dur_lo=2, dur_hi=8, n_mel=80, n_vocab=361, n_speaker=1, min_len_frac=0.6,
-                    max_seq_len=1000, frame_level=False):
-    """LJSpeech-shaped synthetic batch: the reference's 12-tuple minus ids/raw_texts.
-    Returns dict of CPU tensors + python ints."""
-    g = torch.Generator().manual_seed(seed)
-    lo = max(1, int(L * min_len_frac))
-    src_lens = torch.randint(lo, L + 1, (B,), generator=g)
-    src_lens[0] = L
-    src_lens, _ = torch.sort(src_lens, descending=True)
-    texts = torch.randint(1, n_vocab, (B, L), generator=g)
-    durations = torch.randint(dur_lo, dur_hi + 1, (B, L), generator=g)
-    valid = torch.arange(L).unsqueeze(0) < src_lens.unsqueeze(1)
-    texts = texts * valid
-    durations = durations * valid
-    mel_lens = durations.sum(1)
-    while int(mel_lens.max()) > max_seq_len:          # keep max mel_len <= max_seq_len as the survey prescribes
-        durations = torch.clamp(durations - 1, min=0) * valid
-        mel_lens = durations.sum(1)
-    T = int(mel_lens.max())
-    mels = torch.clamp(torch.randn(B, T, n_mel, generator=g) * 2 - 5, -11.5, 2.0)
-    mels = mels * (torch.arange(T).unsqueeze(0) < mel_lens.unsqueeze(1)).unsqueeze(-1)
-    n_var = T if frame_level else L
-    var_valid = (torch.arange(T).unsqueeze(0) < mel_lens.unsqueeze(1)) if frame_level else valid
-    pitches = torch.clamp(torch.randn(B, n_var, generator=g), -2.917, 11.391) * var_valid
-    energies = torch.clamp(torch.randn(B, n_var, generator=g), -1.431, 8.184) * var_valid
-    speakers = torch.randint(0, n_speaker, (B,), generator=g)
-    return dict(speakers=speakers, texts=texts, src_lens=src_lens, max_src_len=L, mels=mels.float(), mel_lens=mel_lens,
-                max_mel_len=T, pitches=pitches.float(), energies=energies.float(), durations=durations)
+from fastspeech2_amd.synthetic import synthetic_batch  # noqa: E402,F401  (the workload generator is product code; re-exported for the tests)

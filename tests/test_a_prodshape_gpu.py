@@ -1,0 +1,247 @@
+"""Parity at PRODUCTION shapes (BASELINE configs[1]: B=48, L=128, T~925, 4+4 layers) - collected first on purpose.
+
+What the bench times is the bf16 path (persistent / ring contraction kernels, bf16 weight-gradient kernels with ragged
+`lens` and split-K atomics, bf16 attention backward) at M = 44 400 rows; the small goldens never reach those dispatch
+branches.  Here:
+  * every contraction shape of the train step, forward and data gradient, bf16 AND fp32, with ragged lengths + tile map, is
+    compared ELEMENTWISE with an exact-product reference (same bf16-rounded operands, fp32/fp64 accumulation): a bf16 result
+    may differ from it by final rounding only (1 ulp = 2^-8 relative) - a wrong tap at one sequence boundary is O(1);
+  * the weight-gradient kernels at M = 44 400 with ragged lens (the 5- and 8-split grids) and bf16 attention backward at
+    S = 925, per-tensor;
+  * the WHOLE train step (forward + loss + backward, dropout off) at full size against the fp64 oracle: fp32 every gradient
+    tensor elementwise (<= 2e-3 of its max), bf16 per-tensor relative Frobenius error with a budget derived from bf16
+    epsilon and depth (reference model/fastspeech2.py:43-110, model/loss.py:19-92).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle.weights import seeded_state_dict, synthetic_batch
+from tests.golden import configs
+from tests.helpers import make_model, oracle_train_case
+
+pytestmark = pytest.mark.gpu
+B, L = 48, 128
+BF16_ULP = 2.0 ** -8
+
+
+def _ops():
+    from fastspeech2_amd import ops
+    return ops
+
+
+def ragged_lens(S, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(int(0.55 * S), S + 1, (B,), generator=g)
+    lens[0] = S
+    return torch.sort(lens, descending=True)[0].to(torch.int32)
+
+
+def conv_ref_gpu(x, w_tap_major, bias, S, pad, lens=None):
+    """exact-product reference on the device: y[m] = sum_j x[m + j - pad] @ W[:, j, :].T (+bias), taps outside the row's own
+    sequence contribute 0; fp32 operands (bf16 values are exact in fp32), fp32 matmuls, summed over taps in fp64."""
+    Bq = x.shape[0] // S
+    k = w_tap_major.shape[1]
+    xs = x.float().view(Bq, S, -1)
+    y = torch.zeros(Bq, S, w_tap_major.shape[0], device=x.device, dtype=torch.float64)
+    for j in range(k):
+        sh = j - pad
+        lo, hi = max(0, -sh), min(S, S - sh)
+        if hi <= lo:
+            continue
+        y[:, lo:hi] += (xs[:, lo + sh:hi + sh] @ w_tap_major[:, j, :].float().t()).double()
+    if bias is not None:
+        y += bias.double()
+    y = y.view(Bq * S, -1)
+    if lens is not None:
+        pad_rows = (torch.arange(S, device=x.device).unsqueeze(0) >= lens.to(x.device).unsqueeze(1)).reshape(-1)
+        y[pad_rows] = 0
+    return y
+
+
+def assert_rounding_only(y, ref, dtype, what):
+    """|y - ref| <= 1 ulp of the storage type relative to |ref| (+ an absolute floor for cancelling sums)."""
+    ref = ref.double()
+    scale = ref.abs().max().item()
+    ulp = BF16_ULP if dtype == torch.bfloat16 else 2.0 ** -20
+    err = (y.double() - ref).abs()
+    bound = ulp * ref.abs() + (2e-4 if dtype == torch.bfloat16 else 2e-5) * scale
+    bad = (err > bound)
+    assert not bad.any(), (what, int(bad.sum()), err.max().item(), scale)
+
+
+# (name, Cin, Cout, k, S): every contraction of the 4+4 train step that runs at M = B*S rows
+SHAPES = [("ffn w_1 k9", 256, 1024, 9, 925), ("ffn w_2 k1", 1024, 256, 1, 925), ("qkv", 256, 768, 1, 925), ("fc", 256, 256, 1, 925),
+          ("postnet k5", 512, 512, 5, 925), ("postnet in", 80, 512, 5, 925), ("postnet out", 512, 80, 5, 925), ("mel", 256, 80, 1, 925),
+          ("enc w_1 k9", 256, 1024, 9, 128), ("predictor k3", 256, 256, 3, 128)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("name,Cin,Cout,k,S", SHAPES)
+def test_contraction_forward_and_dgrad_production_shapes(dev, dtype, name, Cin, Cout, k, S):
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(ord(c) for c in name))
+    M = B * S
+    pad = (k - 1) // 2
+    lens = ragged_lens(S)
+    x = torch.randn(M, Cin, generator=g).to(dev).to(dtype)
+    w = (torch.randn(Cout, k, Cin, generator=g) / math.sqrt(Cin * k)).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    wf, wd = ops.pack_weight(w, dtype)
+    lens_d = lens.to(dev)
+    tmap = ops.tile_map(lens_d, B, S)
+    n_real = int(tmap[0].item())
+    ntm = (M + 255) // 256
+    assert 0 < n_real <= ntm and sorted(tmap[1:].tolist()) == list(range(ntm))       # a permutation: real first, padded last
+    # forward: bias + ReLU, with and without lens / tile map (the persistent kernel needs the map; without it the ring / 128^2 run)
+    ref = torch.relu(conv_ref_gpu(x, wf, bias, S, pad))
+    ref_l = ref.clone()
+    ref_l[(torch.arange(S, device=dev).unsqueeze(0) >= lens_d.unsqueeze(1)).reshape(-1)] = 0
+    for use_lens, use_map in ((False, False), (True, False), (True, True)):
+        y = ops.conv_gemm(x, wf, bias, S, taps=k, pad=pad, act=ops.ACT_RELU, lens=lens_d if use_lens else None,
+                          tmap=tmap if use_map else None)
+        assert_rounding_only(y, ref_l if use_lens else ref, dtype, (name, "fwd", use_lens, use_map))
+    # data gradient (tap-flipped pack, pad' = k-1-pad) with the fused residual add and with the ReLU gate
+    dy = torch.randn(M, Cout, generator=g).to(dev).to(dtype)
+    res = torch.randn(M, Cin, generator=g).to(dev).to(dtype)
+    dref = conv_ref_gpu(dy, wd, None, S, (k - 1) - pad, lens=lens_d)
+    valid = (torch.arange(S, device=dev).unsqueeze(0) < lens_d.unsqueeze(1)).reshape(-1, 1)
+    dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, res=res, lens=lens_d, tmap=tmap)
+    assert_rounding_only(dx, (dref + res.double()) * valid, dtype, (name, "dgrad+res"))
+    dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, act=ops.ACT_GATE, res=res, lens=lens_d, tmap=tmap)
+    assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)) * valid, dtype, (name, "dgrad gate"))
+
+
+@pytest.mark.parametrize("Cin,Cout,k", [(256, 1024, 9), (1024, 256, 1), (512, 512, 5), (256, 768, 1), (80, 512, 5)])
+def test_weight_gradient_production_shapes_bf16(dev, Cin, Cout, k):
+    """conv_wgrad_bf16_kernel<3,0,8> / <3,2,8> / <1,0,4> at M = 44 400 with ragged lens: the split-K grids the bench runs."""
+    ops = _ops()
+    S, pad = 925, (k - 1) // 2
+    M = B * S
+    g = torch.Generator().manual_seed(Cin + k)
+    lens = ragged_lens(S, seed=9).to(dev)
+    valid = (torch.arange(S, device=dev).unsqueeze(0) < lens.unsqueeze(1)).reshape(-1, 1)
+    x = torch.randn(M, Cin, generator=g).to(dev).to(torch.bfloat16)
+    dy = (torch.randn(M, Cout, generator=g).to(dev) * valid).to(torch.bfloat16)       # contract: gradient rows >= lens are zero
+    dw = torch.zeros(Cout, k, Cin, device=dev)
+    db = torch.zeros(Cout, device=dev)
+    ops.conv_wgrad(dy, x, dw, S, taps=k, pad=pad, lens=lens, dbias=db)
+    xs, dys = x.float().view(B, S, Cin), dy.float().view(B, S, Cout)
+    ref = torch.zeros(Cout, k, Cin, device=dev, dtype=torch.float64)
+    for j in range(k):
+        sh = j - pad
+        lo, hi = max(0, -sh), min(S, S - sh)
+        ref[:, j, :] = torch.einsum("bsn,bsc->nc", dys[:, lo:hi].double(), xs[:, lo + sh:hi + sh].double())
+    scale = ref.abs().max().item()
+    err = (dw.double() - ref).abs().max().item()
+    assert err <= 1e-4 * scale, (err, scale)                       # exact bf16 products, fp32 accumulate + atomics
+    fro = ((dw.double() - ref).norm() / ref.norm()).item()
+    assert fro <= 2e-5, fro
+    bref = dys.double().sum((0, 1))
+    assert (db.double() - bref).abs().max().item() <= 1e-4 * bref.abs().max().item()
+
+
+def test_attention_backward_bf16_at_full_length(dev):
+    from tests.test_ops_gpu import attn_ref
+    ops = _ops()
+    S, H = 925, 2
+    g = torch.Generator().manual_seed(3)
+    lens = ragged_lens(S, seed=11)
+    valid = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).reshape(-1)
+    Bq = 8                                                                 # the reference needs B*H*S*S fp64 scores on the host
+    qkv = torch.randn(Bq * S, 3 * H * 128, generator=g)
+    dctx = torch.randn(Bq * S, H * 128, generator=g)
+    dctx[~valid[:Bq * S]] = 0
+    qd, dd = qkv.to(dev).to(torch.bfloat16), dctx.to(dev).to(torch.bfloat16)
+    qr = qd.float().cpu().double().requires_grad_(True)
+    ref = attn_ref(qr, lens[:Bq], Bq, S, H)
+    ref.backward(dd.float().cpu().double())
+    ctx, lse = ops.attn_fwd(qd, lens[:Bq].to(dev), Bq, S, H)
+    dq = ops.attn_bwd(qd, ctx, dd, lse, lens[:Bq].to(dev), Bq, S, H).float().cpu().double()
+    v = valid[:Bq * S]
+    fro_c = ((ctx.float().cpu().double()[v] - ref.detach()[v]).norm() / ref.detach()[v].norm()).item()
+    print(f"attention S=925 bf16: ctx rel-Frobenius {fro_c:.2e}")
+    assert fro_c <= 6e-3, fro_c                                            # one bf16 rounding of P and of the output
+    gref = qr.grad
+    for name, sl in (("dq", slice(0, 256)), ("dk", slice(256, 512)), ("dv", slice(512, 768))):
+        fro = ((dq[v][:, sl] - gref[v][:, sl]).norm() / gref[v][:, sl].norm()).item()
+        print(f"attention S=925 bf16: {name} rel-Frobenius {fro:.2e}")
+        assert fro <= 1.2e-2, (name, fro)                                  # bf16 P, dS and ctx feed the five products
+    assert not dq[~v].any()
+
+
+# ------------------------------------------------------------------------------------------------ whole train step
+@pytest.fixture(scope="module")
+def full_case():
+    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4, dropout=False)
+    model = make_model(pcfg, mcfg, "fp32")
+    sd = seeded_state_dict(model.state_dict(), 2025)
+    b = synthetic_batch(1234, B, L, dur_lo=4, dur_hi=10, min_len_frac=0.75)
+    assert b["max_mel_len"] > 850
+    oout, olosses, ograds, _ = oracle_train_case(pcfg, mcfg, sd, b, dtype=torch.float64)
+    return pcfg, mcfg, sd, b, oout, olosses, ograds
+
+
+def _train_step(dev, pcfg, mcfg, sd, b, cdt):
+    from tests.test_model_gpu import run_train
+    model = make_model(pcfg, mcfg, cdt)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    model.disable_dropout = True
+    out, losses = run_train(model, pcfg, mcfg, b, dev)
+    grads = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None}
+    return out, losses, grads
+
+
+def test_full_size_train_step_fp32_matches_fp64_oracle_elementwise(dev, full_case):
+    pcfg, mcfg, sd, b, oout, olosses, ograds = full_case
+    out, losses, grads = _train_step(dev, pcfg, mcfg, sd, b, "fp32")
+    assert torch.equal(out[9].cpu(), oout[9]) and torch.equal(out[7].cpu(), oout[7])
+    for i in (0, 1):
+        l1 = (out[i].detach().float().cpu().double() - oout[i].detach()).abs().mean().item()
+        assert l1 < 1e-4, (i, l1)                                           # north_star bar
+    for a, o in zip(losses, olosses):
+        assert abs(a.item() - o.item()) <= 1e-5 * max(1.0, abs(o.item()))
+    assert sorted(grads) == sorted(ograds)
+    for n, og in ograds.items():
+        if n.endswith("w_ks.bias"):                                         # softmax is shift-invariant: true gradient 0, rounding noise
+            continue
+        scale = og.abs().max().item()
+        err = (grads[n] - og).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-9, (n, err, scale)
+        fro = ((grads[n] - og).norm() / (og.norm() + 1e-30)).item()
+        assert fro <= 1e-3, (n, fro)
+
+
+def test_full_size_train_step_bf16_per_tensor_budget(dev, full_case):
+    """bf16 storage + bf16 MFMA (fp32 accumulate / statistics / master weights) against the fp64 oracle.  Budget: every stored
+    activation carries a relative rounding error <= 2^-9; a gradient tensor sees ~2 x depth such roundings that add in
+    quadrature across independent elements -> per-tensor relative Frobenius error well under 2^-9 * sqrt(2 * 8 * 4) ~ 1.6e-2;
+    measured values are printed (pytest -s) and the bars sit at <= 1e-2 for weights, 2e-2 for the tiny bias / LayerNorm vectors
+    whose true gradients are sums of cancelling terms."""
+    pcfg, mcfg, sd, b, oout, olosses, ograds = full_case
+    out, losses, grads = _train_step(dev, pcfg, mcfg, sd, b, "bf16")
+    assert torch.equal(out[9].cpu(), oout[9])
+    valid = (~oout[7]).unsqueeze(-1)
+    nval = valid.sum().item() * 80
+    for i in (0, 1):
+        l1 = ((out[i].detach().float().cpu().double() - oout[i].detach()).abs() * valid).sum().item() / nval
+        print(f"bf16 full-size valid-frame mel L1 [{i}] = {l1:.3e}")
+        assert l1 <= 2e-2, (i, l1)
+    for a, o in zip(losses, olosses):
+        assert abs(a.item() - o.item()) <= 1e-2 * max(1.0, abs(o.item())), (a.item(), o.item())
+    worst = []
+    for n, og in ograds.items():
+        if n.endswith("w_ks.bias"):
+            continue
+        fro = ((grads[n] - og).norm() / (og.norm() + 1e-30)).item()
+        worst.append((fro, n))
+        small = og.numel() <= 1024
+        # conv biases in front of BatchNorm have a TRUE gradient of zero (the batch mean absorbs them): compare absolutely
+        if "postnet" in n and n.endswith("conv.bias"):
+            assert grads[n].abs().max().item() <= 1e-2 * max(g.abs().max().item() for g in ograds.values()), n
+            continue
+        assert fro <= (2e-2 if small else 1e-2), (n, fro)
+    worst.sort(reverse=True)
+    print("bf16 full-size per-tensor relative Frobenius error, worst 8:", [(f"{f:.2e}", n) for f, n in worst[:8]])

@@ -36,7 +36,7 @@ def test_version_and_error_string():
 def test_bad_arguments_are_rejected_before_launch():
     """FS2_EINVAL (-1) -> ValueError, FS2_EDTYPE (-2) -> TypeError: mirrors the reference's assert/ValueError style."""
     with pytest.raises(ValueError):
-        _lib.call("fs2_conv_gemm", None, 0, None, None, None, 0, None, 0, None, 0, 0, 0, 0, 1, 1, 0, 0, 0.0, 0, 0.0, 0, 1.0,
+        _lib.call("fs2_conv_gemm", None, 0, None, None, None, 0, None, 0, None, None, 0, 0, 0, 0, 1, 1, 0, 0, 0.0, 0, 0.0, 0, 1.0,
                   0, None)
     with pytest.raises((TypeError, ValueError)):
         _lib.call("fs2_cast", None, 7, None, 9, 16, None)

@@ -29,12 +29,38 @@ def test_bench_line_contract(dev):
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
-    assert r["kernel"].startswith("conv_gemm_ring_kernel") and r["launches_per_step"] == 24 and r["avg_launch_us"] > 0
+    assert r["kernel"].startswith("conv_gemm_p_kernel") and r["launches_per_step"] >= 24 and r["avg_launch_us"] > 0
+    assert 0 < r["frac_valid_rows"] <= r["frac"]                           # FLOPs of valid rows only (fully padded tiles are skipped)
     assert abs(r["gflop_per_launch"] * r["launches_per_step"] / r["kernel_ms_per_step"] - r["achieved"]) < 0.02 * r["achieved"]
     assert r["traffic"] is None or r["traffic"]["bytes_per_launch"] > 0
+    # tamper evidence + measurement quality: the shipped library, no development variables, the timed
+    # window repeated and the median reported, the reference's own arithmetic (fp32) as a secondary figure of the same line
+    cfg = d["config"]
+    assert cfg["library"] == "fastspeech2_amd/libfs2hip.so" and cfg["dev_env"] == []
+    assert cfg["windows"] >= 5 and len(cfg["window_ms_per_step"]) == cfg["windows"]
+    assert sorted(cfg["window_ms_per_step"])[cfg["windows"] // 2] == d["ms_per_step"]
+    assert cfg["fp32_ms_per_step"] > d["ms_per_step"] and 0.05 < cfg["fp32_frac_of_f32_peak"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "mel-frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 100 * c["value"]
+
+
+def test_bench_refuses_development_switches(dev):
+    env = dict(os.environ, FS2_GEMM_ABL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 3 and "FS2_GEMM_ABL" in out.stderr
+
+
+def test_bench_synth_line_has_roofline(dev):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "synth", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][0])
+    assert d["higher_is_better"] is False and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["kernel"].startswith("conv_") and r["launches_per_step"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
 def test_bench_two_ranks_shared_gpu(dev):
@@ -53,5 +79,5 @@ def test_bench_two_ranks_shared_gpu(dev):
     assert d["config"]["parallelism"] == "dp2"
     frames_per_step = d["value"] * d["ms_per_step"] * 1e-3                  # whole-job: both ranks' valid frames
     assert 2 * 0.75 * 48 * 925 < frames_per_step <= 2 * 48 * 925 * 1.001, frames_per_step
-    assert d["roofline"]["kernel"].startswith("conv_gemm_ring_kernel") and d["roofline"]["launches_per_step"] == 24
+    assert d["roofline"]["kernel"].startswith("conv_gemm_p_kernel") and d["roofline"]["launches_per_step"] >= 24
     assert d["cpu_baseline"] is None                                        # reported at N=1 only
