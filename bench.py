@@ -370,7 +370,7 @@ def main():
             opt._adam_step += 1
             lr = opt.init_lr * opt._get_lr_scale()
             b1, b2 = opt.betas
-            opt._hyper.copy_(torch.tensor([lr, 1 - b1 ** opt._adam_step, 1 - b2 ** opt._adam_step, 0.0]))
+            opt.set_hyper(lr, 1 - b1 ** opt._adam_step, 1 - b2 ** opt._adam_step)
             graph.replay()
         else:
             step()

@@ -272,7 +272,15 @@ class DevicePrefetcher:
             raise StopIteration
         batch, ev = item
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            # the tensors were allocated on the copy stream: tell the caching allocator that the CONSUMER stream uses them, so
+            # that their blocks are not handed back to the copy stream (and overwritten by the next batch's H2D) while step
+            # i's loss / embedding-gradient kernels are still queued (no host sync separates steps: gradient accumulation,
+            # graph replay)
+            for t in batch:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)
         return batch
 
 

@@ -36,7 +36,7 @@ class Engine:
         self.lp_synced = False
         self._pe_cache = {}
         self.seed_counter = torch.zeros(1, device=device, dtype=torch.int64)
-        self.base_seed = 0
+        self.reseed()
         mc = model.model_config
         self.tc = mc["transformer"]
         self.d = self.tc["encoder_hidden"]
@@ -52,6 +52,26 @@ class Engine:
         self._side_keep = []
         self._pack_pending = False
         self._tmaps = {}
+
+    # ------------------------------------------------------------------ dropout stream
+    _SEED_INC = 0x632BE59BD9B4E019 & 0x7FFFFFFFFFFFFFFF
+
+    def reseed(self, seed=None, rank=None, step=0):
+        """Dropout masks are a pure function of (site, element, counter); the counter starts from a mix of the process seed
+        (torch.initial_seed(), i.e. torch.manual_seed / train.py's seed) and the data-parallel rank - replicas draw INDEPENDENT
+        masks like the reference's DataParallel replicas do - and advances once per training forward; `step` fast-forwards it
+        (resume from --restore_step continues the mask sequence instead of replaying it from the start)."""
+        import os
+        if seed is None:
+            seed = torch.initial_seed()
+        if rank is None:
+            rank = int(os.environ.get("RANK", "0"))
+        x = (int(seed) + (rank + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF          # splitmix64 finaliser
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        self.base_seed = x & 0x7FFFFFFFFFFFFFFF
+        self.seed_counter.fill_((self.base_seed + int(step) * self._SEED_INC) & 0x7FFFFFFFFFFFFFFF)
 
     # ------------------------------------------------------------------ weights
     def _flat_view(self, first_name, numel, shape, grad=False):
@@ -358,7 +378,7 @@ class Engine:
         seed_dev = None
         drop = training and not getattr(m, "disable_dropout", False)   # test hook == patching F.dropout in the reference
         if drop:
-            ops.bump_counter(self.seed_counter, 0x632BE59BD9B4E019 & 0x7FFFFFFFFFFFFFFF)
+            ops.bump_counter(self.seed_counter, self._SEED_INC)
             seed_dev = self.seed_counter.clone()
         p_enc = self.tc["encoder_dropout"] if drop else 0.0
         p_dec = self.tc["decoder_dropout"] if drop else 0.0
@@ -584,5 +604,8 @@ class _FS2Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dmel, dpost, dp, de, dlogd):
-        ctx.engine.backward(ctx.sv, dmel, dpost, dp, de, dlogd)
+        sv, ctx.sv = ctx.sv, None            # release the saved activations with this backward, not with the next forward
+        if sv is None:
+            raise RuntimeError("FastSpeech2 backward called twice on the same forward (saved activations were released)")
+        ctx.engine.backward(sv, dmel, dpost, dp, de, dlogd)
         return (None, None) + (None,) * ctx.n

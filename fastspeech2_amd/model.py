@@ -199,6 +199,23 @@ class FastSpeech2(nn.Module):
             compute_dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
                              "bfloat16": torch.bfloat16}[compute_dtype]
         self.compute_dtype = compute_dtype
+        # shape limits of the hand-written kernels, checked at CONSTRUCTION (not in the middle of the first backward)
+        vp = model_config["variance_predictor"]
+        problems = []
+        for side in ("encoder", "decoder"):
+            if d % tc[side + "_head"] or d // tc[side + "_head"] != 128:
+                problems.append(f"{side}_hidden / {side}_head = {d}/{tc[side + '_head']} (attention kernels: head size 128 only)")
+        if d % 256:
+            problems.append(f"encoder_hidden = {d} (LayerNorm backward: multiples of 256)")
+        if vp["filter_size"] % 256:
+            problems.append(f"variance_predictor.filter_size = {vp['filter_size']} (LayerNorm backward: multiples of 256)")
+        if tc["conv_filter_size"] % 8 or d % 8:
+            problems.append("channel counts must be multiples of 8 (16-byte rows)")
+        if len(ks) != 2 or any(k % 2 == 0 for k in ks):
+            problems.append(f"conv_kernel_size = {ks} (two odd kernel sizes)")
+        if problems:
+            raise ValueError("FastSpeech2: configuration outside the shapes the HIP kernels are built for: " + "; ".join(problems))
+        self._dropout_step = 0          # resume: how many training forwards came before (fast-forwards the dropout counter)
         self._engine = None
         self._flat = None
         self._flat_grad = None
@@ -281,6 +298,7 @@ class FastSpeech2(nn.Module):
         self._flat, self._flat_grad, self._flat_offsets = flat, grad, offsets
         self._flat_names = [n for n, _ in pairs]
         self._engine = Engine(self, device)
+        self._engine.reseed(step=self._dropout_step)
 
     @staticmethod
     def _view(buf, offset, shape):
@@ -420,6 +438,12 @@ class ScheduledOptim:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
             self._hyper = torch.zeros(4, device=flat.device, dtype=torch.float32)
+            # lr / bias corrections travel through a ring of PINNED host slots: the copy is truly asynchronous (no per-step
+            # host sync, no reliance on the runtime staging a pageable temporary) and a slot is rewritten only after the
+            # copy that read it has executed
+            self._hyper_host = torch.zeros(16, 4, dtype=torch.float32).pin_memory() if flat.is_cuda else None
+            self._hyper_ev = [None] * 16
+            self._hyper_i = 0
             self._nsq = torch.zeros(1, device=flat.device, dtype=torch.float32)
             self._nsq_ws = torch.empty(1024, device=flat.device, dtype=torch.float32)
             if self._pending_state is not None:
@@ -433,9 +457,25 @@ class ScheduledOptim:
         self._adam_step += 1
         lr = self.init_lr * self._get_lr_scale()
         b1, b2 = self.betas
-        self._hyper.copy_(torch.tensor([lr, 1 - b1 ** self._adam_step, 1 - b2 ** self._adam_step, 0.0]), non_blocking=True)
+        self.set_hyper(lr, 1 - b1 ** self._adam_step, 1 - b2 ** self._adam_step)
         self.apply_update(zero_grad=zero_grad)
         self.last_lr = lr
+
+    def set_hyper(self, lr, bc1, bc2):
+        """[lr, 1 - b1^t, 1 - b2^t, 0] -> device (read by the Adam kernel), stream-ordered, without a host sync."""
+        if self._hyper_host is None:
+            self._hyper.copy_(torch.tensor([lr, bc1, bc2, 0.0]))
+            return
+        i = self._hyper_i
+        self._hyper_i = (i + 1) % len(self._hyper_ev)
+        if self._hyper_ev[i] is not None:
+            self._hyper_ev[i].synchronize()
+        h = self._hyper_host[i]
+        h[0], h[1], h[2], h[3] = lr, bc1, bc2, 0.0
+        self._hyper.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_ev[i] = ev
 
     def apply_update(self, zero_grad=False):
         """The capturable part: ||g||^2, then clip+Adam over the flat buffers (reads lr / bias corrections from device).

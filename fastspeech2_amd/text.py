@@ -56,6 +56,12 @@ def _clean(text, cleaner_names):
         if name == "english_cleaners":
             # number / abbreviation expansion needs `inflect` + `unidecode` (absent here); inside the training and
             # batch-synthesis path all text is already phonemes in braces, so only the plain normalisation applies.
+            # Free text OUTSIDE braces that the reference's english_cleaners would rewrite (digits, "$", "Mr." ...) would map to
+            # different ids here: say so instead of degrading silently.
+            if re.search(r"[0-9$£]|\b(mrs?|dr|st|co|jr|maj|gen|drs|rev|lt|hon|sgt|capt|esq|ltd|col|ft)\.", text, re.I) or not text.isascii():
+                import warnings
+                warnings.warn("english_cleaners: number / abbreviation / unicode expansion is not built (needs inflect + unidecode); "
+                              f"text outside {{}} is only lower-cased: {text[:40]!r}", stacklevel=3)
             text = basic_cleaners(text)
         elif name in _CLEANERS:
             text = _CLEANERS[name](text)

@@ -27,8 +27,12 @@ def get_model(args, configs, device, train=False, compute_dtype=None):
     ckpt = None
     if args.restore_step:
         ckpt_path = os.path.join(train_config["path"]["ckpt_path"], "{}.pth.tar".format(args.restore_step))
-        ckpt = torch.load(ckpt_path, map_location="cpu")
+        # checkpoints written by the reference hold a numpy scalar (param_groups[0]["lr"]: init_lr is np.power(...),
+        # model/optimizer.py:19,50) which torch >= 2.6's default weights_only unpickler rejects; they are the user's own
+        # training artefacts, loaded the way the reference loads them (utils/model.py:20)
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
         model.load_state_dict(ckpt["model"])
+        model._dropout_step = int(args.restore_step)      # dropout masks continue their sequence instead of replaying it
     if train:
         scheduled_optim = ScheduledOptim(model, train_config, model_config, args.restore_step)
         if args.restore_step:
@@ -60,7 +64,7 @@ def get_vocoder(config, device, hifigan_dir="hifigan", compute_dtype="fp32", all
     ckpt_path = os.path.join(hifigan_dir, {"LJSpeech": "generator_LJSpeech.pth.tar",
                                            "universal": "generator_universal.pth.tar"}[speaker])
     if os.path.exists(ckpt_path):
-        ckpt = torch.load(ckpt_path, map_location="cpu")
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
         vocoder.load_state_dict(ckpt["generator"])
     elif not allow_random_init:
         raise FileNotFoundError(ckpt_path)

@@ -163,3 +163,50 @@ def make_raw_corpus(root, seed=5, sr=22050, hop=256):
                              "pitch": {"feature": "phoneme_level", "normalization": True},
                              "energy": {"feature": "phoneme_level", "normalization": True}}}
     return cfg, tables
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints (resume tests)
+CKPT_SEED, CKPT_B, CKPT_L = 606, 3, 14
+CKPT_CFG = dict(dec_layers=2, enc_layers=2)
+
+
+def oracle_written_checkpoint(path, steps=2):
+    """The file the reference's train loop writes after `steps` optimiser steps (train.py:82-97,152-161), rebuilt WITHOUT the
+    reference: oracle forward + FastSpeech2Loss restatement, torch.nn.utils.clip_grad_norm_, torch.optim.Adam over the parameters
+    in the reference's parameters() order (pinned by tests/golden/state_schema.json) with the reference's LR schedule
+    (model/optimizer.py:33-51).  tests/test_checkpoint_cpu.py proves it equal to the file the live reference writes;
+    tests/golden/ckpt_resume.npz carries the reference-written file's per-tensor checksums for boxes without the reference.
+    Returns (pcfg, mcfg, batch, ckpt dict)."""
+    pcfg, mcfg = configs.make(dropout=False, **CKPT_CFG)
+    from fastspeech2_amd.model import FastSpeech2
+    template = FastSpeech2(pcfg, mcfg)
+    names = [n for n, _ in template.named_parameters()]
+    seeded = seeded_state_dict(template.state_dict(), CKPT_SEED)
+    sd = {k: seeded[k].clone() for k in template.state_dict()}          # state_dict() order, as torch.save sees it
+    params = []
+    for n, p in template.named_parameters():
+        sd[n].requires_grad_(p.requires_grad)
+        params.append(sd[n])
+    tc = configs.TRAIN["optimizer"]
+    opt = torch.optim.Adam(params, betas=tc["betas"], eps=tc["eps"], weight_decay=tc["weight_decay"])
+    init_lr = np.power(mcfg["transformer"]["encoder_hidden"], -0.5)
+    b = synthetic_batch(CKPT_SEED + 1, CKPT_B, CKPT_L)
+    bn = {k: v for k, v in sd.items() if "running_" in k}
+    for step in range(1, steps + 1):
+        out = O.fastspeech2_forward(sd, mcfg, pcfg, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"],
+                                    b["max_mel_len"], b["pitches"], b["energies"], b["durations"], training=True, dropout=False,
+                                    bn_buffers=bn)
+        loss = O.fastspeech2_loss(pcfg, (b["mels"], b["pitches"], b["energies"], b["durations"]), out)[0]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, tc["grad_clip_thresh"])
+        lr = init_lr * np.min([np.power(step, -0.5), np.power(tc["warm_up_step"], -1.5) * step])
+        for g in opt.param_groups:
+            g["lr"] = lr                                     # a numpy scalar, as in the reference (optimizer.py:19,50)
+        opt.step()
+        opt.zero_grad()
+        for k in sd:
+            if k.endswith("num_batches_tracked"):
+                sd[k] += 1                                   # nn.BatchNorm1d counts training forwards
+    ckpt = {"model": {k: v.detach().clone() for k, v in sd.items()}, "optimizer": opt.state_dict()}
+    torch.save(ckpt, path)
+    return pcfg, mcfg, b, ckpt, names

@@ -1,0 +1,138 @@
+"""(f)3 released-checkpoint compatibility, host side (reference train.py:152-161, utils/model.py:15-28, model/optimizer.py:19-31).
+
+Runs where /root/reference exists (the build container): the LIVE reference writes `2.pth.tar` after two optimiser steps; the
+product restores it through get_model(--restore_step 2) - weights, Adam moments, step counters, learning-rate schedule - and the
+product's own checkpoint loads back into the reference's model and torch.optim.Adam.  Also pins the oracle-written stand-in the
+GPU resume test uses (tests/helpers.oracle_written_checkpoint) to the reference-written file, tensor by tensor."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import configs
+from tests.helpers import load_golden, oracle_written_checkpoint
+
+REF = "/root/reference"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the live reference at /root/reference")
+
+
+@pytest.fixture(scope="module")
+def ref_run(tmp_path_factory):
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ckpt as G
+    d = tmp_path_factory.mktemp("refckpt")
+    r = G.reference_two_steps(str(d))
+    r["dir"], r["G"] = str(d), G
+    return r
+
+
+def _args(step):
+    return types.SimpleNamespace(restore_step=step)
+
+
+@needs_ref
+def test_reference_written_checkpoint_restores_into_the_product(ref_run):
+    from fastspeech2_amd.utils import get_model
+    pcfg, mcfg = configs.make(dropout=False, **ref_run["G"].CFG)
+    tcfg = dict(configs.TRAIN, path=dict(configs.TRAIN["path"], ckpt_path=ref_run["dir"]))
+    dev = torch.device("cpu")
+    model, opt = get_model(_args(2), (pcfg, mcfg, tcfg), dev, train=True)
+    ckpt = torch.load(ref_run["path"], map_location="cpu", weights_only=False)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ckpt["model"][k]), k
+    model._ensure_flat(dev)
+    opt._ensure()
+    assert opt.current_step == 2 and opt._adam_step == 2
+    params = list(model.parameters())
+    names = {id(p): n for n, p in model.named_parameters()}
+    n_state = 0
+    for i, st in ckpt["optimizer"]["state"].items():
+        p = params[int(i)]
+        off = model._flat_offsets[names[id(p)]]
+        assert torch.equal(model._view(opt._m, off, p.shape), st["exp_avg"]), names[id(p)]
+        assert torch.equal(model._view(opt._v, off, p.shape), st["exp_avg_sq"]), names[id(p)]
+        n_state += 1
+    assert n_state == sum(1 for p in params if p.requires_grad)
+    # the schedule continues at step 3 with the reference's learning rate
+    opt.current_step += 1
+    assert abs(opt.init_lr * opt._get_lr_scale() - ref_run["lr3"]) <= 1e-12 * ref_run["lr3"]
+
+
+@needs_ref
+def test_product_checkpoint_loads_into_the_reference(ref_run, tmp_path):
+    """train.py:152-161 on the product side -> the reference's FastSpeech2.load_state_dict (strict) and torch.optim.Adam."""
+    from fastspeech2_amd.utils import get_model
+    G = ref_run["G"]
+    pcfg, mcfg = configs.make(dropout=False, **G.CFG)
+    tcfg = dict(configs.TRAIN, path=dict(configs.TRAIN["path"], ckpt_path=ref_run["dir"]))
+    model, opt = get_model(_args(2), (pcfg, mcfg, tcfg), torch.device("cpu"), train=True)
+    model._ensure_flat(torch.device("cpu"))
+    opt._ensure()
+    path = tmp_path / "2.pth.tar"
+    torch.save({"model": model.state_dict(), "optimizer": opt.state_dict()}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from model import ScheduledOptim
+        ref_model = G.MG.build_reference(pcfg, mcfg)
+        missing = ref_model.load_state_dict(ck["model"], strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        ropt = ScheduledOptim(ref_model, configs.TRAIN, mcfg, 2)
+        ropt.load_state_dict(ck["optimizer"])                # utils/model.py:26 (torch.optim.Adam.load_state_dict validates the groups)
+    finally:
+        os.chdir(cwd)
+    orig = torch.load(ref_run["path"], map_location="cpu", weights_only=False)["optimizer"]["state"]
+    got = ropt._optimizer.state_dict()["state"]
+    assert sorted(got) == sorted(orig)
+    for i in orig:
+        assert float(got[i]["step"]) == float(orig[i]["step"]) == 2.0
+        assert torch.equal(got[i]["exp_avg"], orig[i]["exp_avg"]) and torch.equal(got[i]["exp_avg_sq"], orig[i]["exp_avg_sq"])
+
+
+@needs_ref
+def test_oracle_written_checkpoint_equals_reference_written(ref_run, tmp_path):
+    _, _, _, ock, names = oracle_written_checkpoint(str(tmp_path / "2.pth.tar"))
+    rck = torch.load(ref_run["path"], map_location="cpu", weights_only=False)
+    assert list(ock["model"]) == list(rck["model"]) and names == ref_run["param_names"]
+    for k, v in rck["model"].items():
+        if v.is_floating_point():
+            assert torch.allclose(ock["model"][k], v, rtol=1e-5, atol=1e-7), k
+        else:
+            assert torch.equal(ock["model"][k], v), k
+    assert sorted(ock["optimizer"]["state"]) == sorted(rck["optimizer"]["state"])
+    for i, st in rck["optimizer"]["state"].items():
+        o = ock["optimizer"]["state"][i]
+        assert float(o["step"]) == float(st["step"])
+        for key in ("exp_avg", "exp_avg_sq"):
+            scale = st[key].abs().max().item()
+            assert (o[key] - st[key]).abs().max().item() <= 2e-4 * scale + 1e-12, (names[int(i)], key)
+    go, gr = ock["optimizer"]["param_groups"][0], rck["optimizer"]["param_groups"][0]
+    assert go["params"] == gr["params"] and abs(go["lr"] - gr["lr"]) <= 1e-12 * gr["lr"] and tuple(go["betas"]) == tuple(gr["betas"])
+
+
+def test_oracle_written_checkpoint_matches_reference_checksums(tmp_path):
+    """runs everywhere (no reference needed): the stand-in file agrees with the per-tensor checksums of the reference-written one."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    g = load_golden("ckpt_resume")
+    _, _, _, ock, names = oracle_written_checkpoint(str(tmp_path / "2.pth.tar"))
+    stats = {}
+    for k, v in ock["model"].items():
+        if v.is_floating_point():
+            stats["model:" + k] = v
+    for i, st in ock["optimizer"]["state"].items():
+        stats["exp_avg:" + names[int(i)]] = st["exp_avg"]
+        stats["exp_avg_sq:" + names[int(i)]] = st["exp_avg_sq"]
+    keys = [str(k) for k in g["keys"]]
+    assert sorted(stats) == keys
+    for k, ref in zip(keys, g["stats"]):
+        t = stats[k].double()
+        got = np.array([t.sum().item(), t.abs().sum().item(), t.norm().item()])
+        assert abs(got[2] - ref[2]) <= 2e-4 * ref[2] + 1e-12, (k, got, ref)           # norm
+        assert abs(got[1] - ref[1]) <= 2e-4 * ref[1] + 1e-12, (k, got, ref)           # abs-sum
+    assert float(next(iter(ock["optimizer"]["state"].values()))["step"]) == float(g["adam_step"]) == 2.0
+    assert abs(ock["optimizer"]["param_groups"][0]["lr"] - float(g["lr_in_ckpt"])) <= 1e-12
