@@ -121,7 +121,7 @@ def build(args, device, rank, world, dtype=None):
             b["pitches"] = (torch.clamp(torch.randn(args.batch, L, generator=g), -2.917, 11.391) * sv).float()
             b["energies"] = (torch.clamp(torch.randn(args.batch, L, generator=g), -1.431, 8.184) * sv).float()
     b = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
-    loss_fn = FastSpeech2Loss(pcfg, mcfg, count_reduce=ddp.global_counts if world > 1 else None)
+    loss_fn = FastSpeech2Loss(pcfg, mcfg, count_reduce=ddp.CountExchange() if world > 1 else None)
     opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
     opt._ensure()
     return model, loss_fn, opt, b, pcfg, mcfg
@@ -131,7 +131,11 @@ def make_step(model, loss_fn, opt, b, exchange):
     batch12 = (None, None, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"],
                b["max_mel_len"], b["pitches"], b["energies"], b["durations"])
 
+    T_dec = min(int(b["max_mel_len"]), int(model.model_config["max_seq_len"]))
+
     def fwd_bwd():
+        if loss_fn.count_reduce is not None:                # the valid-position counts travel while the forward pass runs
+            loss_fn.count_reduce.start(b["src_lens"], b["mel_lens"], int(b["max_src_len"]), T_dec)
         out = model(*batch12[2:])
         losses = loss_fn(batch12, out)
         losses[0].backward()
@@ -406,9 +410,18 @@ def main():
         torch.cuda.synchronize()
     frames = b["mel_lens"].sum().to(torch.float64)
     padded = torch.tensor([float(args.batch * b["max_mel_len"])], device=device, dtype=torch.float64)
+    dist_info = {}
     if world > 1:
         dist.all_reduce(frames)
         dist.all_reduce(padded)
+        # data-parallel sanity carried by the line itself: the group really has N ranks on this backend and, after the timed
+        # steps, every replica holds bit-identical parameters (each saw its own batch; only the exchanged gradients couple them)
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+        chk = torch.stack([model.flat_parameters().double().sum(), model.flat_parameters().double().abs().sum()])
+        allchk = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allchk, chk)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "replicas_bit_identical": all(torch.equal(c, allchk[0]) for c in allchk)}
     value = frames.item() * args.steps / dt
     final_loss = float((static_loss if graph is not None else loss).item())
 
@@ -497,7 +510,7 @@ def main():
                        "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),
                        "side_stream_wgrad": bool(model._engine.use_side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
                        "windows": len(window_s), "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in window_s],
-                       "library": lib_used, "dev_env": [], **fp32},
+                       "library": lib_used, "dev_env": [], **fp32, **dist_info},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -19,12 +19,20 @@ import torch.distributed as dist
 
 
 class GradExchange:
-    def __init__(self, flat_grad, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True):
+    def __init__(self, flat_grad, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True, tail_bucket_bytes=None,
+                 tail_bytes=48 << 20):
+        """Buckets are `bucket_bytes` except over the LAST `tail_bytes` of the flat buffer (the encoder's gradients, final only
+        when backward ends), which travel in `tail_bucket_bytes` pieces (default bucket_bytes / 4): whatever is still in flight
+        when backward finishes is exposed in front of the clip + Adam pass (it needs the norm of ALL gradients, so it cannot
+        start per bucket), and a smaller last piece makes that exposure a quarter of a bucket instead of a whole one."""
         self.flat = flat_grad
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.n = flat_grad.numel()
+        tb = tail_bucket_bytes if tail_bucket_bytes is not None else max(1, bucket_bytes // 4)
+        self.tail_elems = max(1, tb // flat_grad.element_size())
+        self.tail_start = max(0, self.n - tail_bytes // flat_grad.element_size())
         self.cuda = flat_grad.is_cuda
         self.overlap = overlap and self.cuda
         # high priority: the collective's few workgroups must get CUs while backward still fills the device, otherwise the
@@ -61,9 +69,12 @@ class GradExchange:
         if self.world == 1:
             return
         end = min(end, self.n)
-        while end - self.sent >= self.bucket_elems:
-            self._launch(self.sent, self.sent + self.bucket_elems, producers)
-            self.sent += self.bucket_elems
+        while True:
+            size = self.bucket_elems if self.sent + self.bucket_elems <= self.tail_start else self.tail_elems
+            if end - self.sent < size:
+                break
+            self._launch(self.sent, self.sent + size, producers)
+            self.sent += size
 
     def finish(self):
         """Flush the tail bucket and make the compute stream wait for all collectives."""
@@ -78,6 +89,45 @@ class GradExchange:
         if self.cuda and self.overlap:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
+
+
+class CountExchange:
+    """The loss's valid-position counts, all-reduced AHEAD of the forward pass.
+
+    The counts depend only on the batch's lengths (sum of min(src_len, L), sum of min(mel_len, T)), so `start` launches their
+    all-reduce on the communication stream as soon as the batch is on the device and the train step's forward overlaps it;
+    the instance is passed to FastSpeech2Loss as `count_reduce` and hands the result over (the compute stream waits for the
+    collective's event, the host never blocks).  Without a pending `start` it falls back to the blocking `global_counts`."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._pending = None
+        self._stream = None
+
+    def start(self, src_lens, mel_lens, L, T):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        c = torch.stack([src_lens.to(torch.int64).clamp(max=L).sum(), mel_lens.to(torch.int64).clamp(max=T).sum()]).float()
+        if c.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=c.device, priority=-1)
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                h = dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            c.record_stream(self._stream)
+        else:
+            h = dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending = (c, h)
+
+    def __call__(self, counts):
+        if self._pending is None:
+            return global_counts(counts, self.group)
+        c, h = self._pending
+        self._pending = None
+        h.wait()                                     # device tensors: makes the CURRENT stream wait for the collective
+        if c.is_cuda:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        return c / dist.get_world_size(self.group)
 
 
 def global_counts(counts, group=None):

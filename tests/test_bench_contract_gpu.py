@@ -76,7 +76,8 @@ def test_bench_two_ranks_shared_gpu(dev):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 96
-    assert d["config"]["parallelism"] == "dp2"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["replicas_bit_identical"] is True
     frames_per_step = d["value"] * d["ms_per_step"] * 1e-3                  # whole-job: both ranks' valid frames
     assert 2 * 0.75 * 48 * 925 < frames_per_step <= 2 * 48 * 925 * 1.001, frames_per_step
     assert d["roofline"]["kernel"].startswith("conv_gemm_p_kernel") and d["roofline"]["launches_per_step"] >= 24

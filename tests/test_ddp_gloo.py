@@ -60,6 +60,26 @@ def _worker(rank, world, port, q):
         tot = local.clone()
         dist.all_reduce(tot)
         res["loss_err"] = abs((tot / world - global_mean).item())
+        # the same counts exchanged AHEAD of the forward pass (CountExchange.start ... __call__) and the blocking fallback
+        cx = ddp.CountExchange()
+        src_l = lens[rank]
+        mel_l = lens[rank] * 7
+        cx.start(src_l, mel_l, 9, 40)                                    # clamped to the padded lengths L = 9, T = 40
+        got = cx(torch.zeros(2))
+        want_c = torch.stack([lens.clamp(max=9).sum(), (lens * 7).clamp(max=40).sum()]).float() / world
+        res["count_err"] = (got - want_c).abs().max().item()
+        res["count_fallback_err"] = (cx(torch.stack([src_l.clamp(max=9).sum(), mel_l.clamp(max=40).sum()]).float()) - want_c).abs().max().item()
+        # graduated buckets: 1000-element buckets, the last 2500 elements in 250-element pieces
+        flat.copy_(every[rank])
+        ex2 = ddp.GradExchange(flat, world, bucket_bytes=4000, tail_bytes=10000, overlap=False)
+        sizes = []
+        orig_launch = ex2._launch
+        ex2._launch = lambda lo, hi, producers=(): (sizes.append(hi - lo), orig_launch(lo, hi, producers))[1]
+        for end in (3000, 7000, 8300, n):
+            ex2.ready(end)
+        ex2.finish()
+        res["exchange_err3"] = (flat - want).abs().max().item()
+        res["bucket_sizes"] = sizes
 
         # ---- 3. sharding
         lengths = [int(x) for x in torch.randint(10, 200, (64,), generator=torch.Generator().manual_seed(3))]
@@ -89,6 +109,10 @@ def test_world2_gloo_exchange_loss_and_sharding():
         assert out[r]["exchange_err2"] < 1e-6
         assert out[r]["reset"] == (0, 0)
         assert out[r]["loss_err"] < 1e-6
+        assert out[r]["count_err"] == 0 and out[r]["count_fallback_err"] == 0
+        assert out[r]["exchange_err3"] < 1e-6
+        bs = out[r]["bucket_sizes"]
+        assert sum(bs) == 10007 and bs[:7] == [1000] * 7 and all(b == 250 for b in bs[7:-1]) and bs[-1] == 7, bs
     s0, s1 = out[0]["shard"], out[1]["shard"]
     lengths = out[0]["lengths"]
     assert len(s0) == len(s1) == 64 // 16

@@ -61,7 +61,7 @@ def main(args, configs):
         for _, buf in model.named_buffers():
             torch.distributed.broadcast(buf, 0)
         model._invalidate()
-    Loss = FastSpeech2Loss(preprocess_config, model_config, count_reduce=ddp.global_counts if world > 1 else None).to(device)
+    Loss = FastSpeech2Loss(preprocess_config, model_config, count_reduce=ddp.CountExchange() if world > 1 else None).to(device)
     if main_rank:
         print("Number of FastSpeech2 Parameters:", get_param_num(model))
 
@@ -93,6 +93,8 @@ def main(args, configs):
             update = step % grad_acc_step == 0
             if exchange is not None:                    # all-reduce only the micro-step that completes the accumulation
                 model._engine.grad_hook = exchange.ready if update else None
+            if Loss.count_reduce is not None:           # valid-position counts: all-reduced while the forward pass runs
+                Loss.count_reduce.start(batch[4], batch[7], int(batch[5]), min(int(batch[8]), model_config["max_seq_len"]))
             output = model(*(batch[2:]))
             losses = Loss(batch, output)
             total_loss = losses[0] / grad_acc_step
