@@ -21,6 +21,20 @@ def _site_seed(i):
     return (i * _GOLD + 0x1234567) & 0x7FFFFFFFFFFFFFFF
 
 
+def _seed_pair(site, step_seed):
+    """(seed argument, device seed pointer) of a dropout site.  `step_seed` is this forward's position in the dropout stream:
+    a Python int in eager mode (added on the host: no counter kernel, no clone per step) or a device tensor when the step is
+    being captured into a hipGraph (the kernels add *seed_dev, so replays draw fresh masks)."""
+    if step_seed is None or isinstance(step_seed, int):
+        return (_site_seed(site) + (step_seed or 0)) & 0xFFFFFFFFFFFFFFFF, None
+    return _site_seed(site), step_seed
+
+
+def _seed_kw(name, site, step_seed):
+    v, d = _seed_pair(site, step_seed)
+    return {name: v, "seed_dev": d}
+
+
 class _Saved:
     pass
 
@@ -36,6 +50,7 @@ class Engine:
         self.lp_synced = False
         self._pe_cache = {}
         self.seed_counter = torch.zeros(1, device=device, dtype=torch.int64)
+        self.device_seed = False        # True: dropout position read from device memory (graph capture: bench.py --graph 1)
         self.reseed()
         mc = model.model_config
         self.tc = mc["transformer"]
@@ -71,6 +86,7 @@ class Engine:
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
         x ^= x >> 31
         self.base_seed = x & 0x7FFFFFFFFFFFFFFF
+        self._seed_k = int(step)
         self.seed_counter.fill_((self.base_seed + int(step) * self._SEED_INC) & 0x7FFFFFFFFFFFFFFF)
 
     # ------------------------------------------------------------------ weights
@@ -268,12 +284,12 @@ class Engine:
         ctx, lse = ops.attn_fwd(qkv, lens, B, S, n_head, self.d // n_head)
         y1 = self._gemm(W, a + "fc", ctx, S, lens=lens)
         h, mean1, rstd1 = ops.ln_fwd(y1, x, self.P[a + "layer_norm.weight"], self.P[a + "layer_norm.bias"], lens, B, S,
-                                     p_pre=p, seed_pre=_site_seed(site), seed_dev=seed_dev)
+                                     p_pre=p, **_seed_kw("seed_pre", site, seed_dev))
         hid = self._gemm(W, f + "w_1", h, S, taps=ks[0], pad=(ks[0] - 1) // 2, act=ACT_RELU,
                          lens=lens if ks[1] == 1 else None)
         y2 = self._gemm(W, f + "w_2", hid, S, taps=ks[1], pad=(ks[1] - 1) // 2, lens=lens if ks[1] == 1 else None)
         out, mean2, rstd2 = ops.ln_fwd(y2, h, self.P[f + "layer_norm.weight"], self.P[f + "layer_norm.bias"], lens, B, S,
-                                       p_pre=p, seed_pre=_site_seed(site + 1), seed_dev=seed_dev)
+                                       p_pre=p, **_seed_kw("seed_pre", site + 1, seed_dev))
         if keep:
             sv.x, sv.qkv, sv.ctx, sv.lse, sv.z1, sv.mean1, sv.rstd1 = x, qkv, ctx, lse, y1, mean1, rstd1
             sv.h, sv.hid, sv.z2, sv.mean2, sv.rstd2 = h, hid, y2, mean2, rstd2
@@ -286,7 +302,7 @@ class Engine:
         p = sv.p
         dz2, dy2 = ops.ln_bwd(sv.z2, dout, self.P[f + "layer_norm.weight"], lens, sv.mean2, sv.rstd2,
                               G[f + "layer_norm.weight"], G[f + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
-                              p_pre=p, seed_pre=_site_seed(sv.site + 1), seed_dev=seed_dev)
+                              p_pre=p, **_seed_kw("seed_pre", sv.site + 1, seed_dev))
         if dy2 is None:
             dy2 = dz2
         # all gradients below are zero on padded rows (ln_bwd zeroes them) -> lens lets every kernel skip those tiles
@@ -297,7 +313,7 @@ class Engine:
         dh = self._dgemm(W, f + "w_1", dhid, S, taps=ks[0], pad=(ks[0] - 1) // 2, res=dz2, lens=lens)
         dz1, dy1 = ops.ln_bwd(sv.z1, dh, self.P[a + "layer_norm.weight"], lens, sv.mean1, sv.rstd1,
                               G[a + "layer_norm.weight"], G[a + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
-                              p_pre=p, seed_pre=_site_seed(sv.site), seed_dev=seed_dev)
+                              p_pre=p, **_seed_kw("seed_pre", sv.site, seed_dev))
         if dy1 is None:
             dy1 = dz1
         self._wgrad(G[a + "fc.weight"], G[a + "fc.bias"], dy1, sv.ctx, S, lens=lens)
@@ -313,10 +329,10 @@ class Engine:
         sv = _Saved()
         c1 = self._gemm(W, cl + "conv1d_1", x, S, taps=k, pad=(k - 1) // 2, act=ACT_RELU)
         n1, m1, r1 = ops.ln_fwd(c1, None, self.P[cl + "layer_norm_1.weight"], self.P[cl + "layer_norm_1.bias"], None, B, S,
-                                p_post=p, seed_post=_site_seed(site), seed_dev=seed_dev)
+                                p_post=p, **_seed_kw("seed_post", site, seed_dev))
         c2 = self._gemm(W, cl + "conv1d_2", n1, S, taps=k, pad=1, act=ACT_RELU)
         n2, m2, r2 = ops.ln_fwd(c2, None, self.P[cl + "layer_norm_2.weight"], self.P[cl + "layer_norm_2.bias"], None, B, S,
-                                p_post=p, seed_post=_site_seed(site + 1), seed_dev=seed_dev)
+                                p_post=p, **_seed_kw("seed_post", site + 1, seed_dev))
         pred = ops.rowdot_fwd(n2, self.P[pre + "linear_layer.weight"], self.P[pre + "linear_layer.bias"], lens, B, S)
         if keep:
             sv.x, sv.c1, sv.m1, sv.r1, sv.n1, sv.c2, sv.m2, sv.r2, sv.n2 = x, c1, m1, r1, n1, c2, m2, r2, n2
@@ -333,12 +349,12 @@ class Engine:
                              G[pre + "linear_layer.bias"], B, S)
         _, dc2 = ops.ln_bwd(sv.c2, dn2, self.P[cl + "layer_norm_2.weight"], None, sv.m2, sv.r2, G[cl + "layer_norm_2.weight"],
                             G[cl + "layer_norm_2.bias"], B, S, want_d1=False, want_d2=True, p_post=p,
-                            seed_post=_site_seed(sv.site + 1), relu_bwd=True, seed_dev=seed_dev)
+                            relu_bwd=True, **_seed_kw("seed_post", sv.site + 1, seed_dev))
         self._wgrad(G[cl + "conv1d_2.conv.weight"], G[cl + "conv1d_2.conv.bias"], dc2, sv.n1, S, taps=k, pad=1)
         dn1 = self._dgemm(W, cl + "conv1d_2", dc2, S, taps=k, pad=1)
         _, dc1 = ops.ln_bwd(sv.c1, dn1, self.P[cl + "layer_norm_1.weight"], None, sv.m1, sv.r1, G[cl + "layer_norm_1.weight"],
                             G[cl + "layer_norm_1.bias"], B, S, want_d1=False, want_d2=True, p_post=p,
-                            seed_post=_site_seed(sv.site), relu_bwd=True, seed_dev=seed_dev)
+                            relu_bwd=True, **_seed_kw("seed_post", sv.site, seed_dev))
         self._wgrad(G[cl + "conv1d_1.conv.weight"], G[cl + "conv1d_1.conv.bias"], dc1, sv.x, S, taps=k, pad=(k - 1) // 2)
         return self._dgemm(W, cl + "conv1d_1", dc1, S, taps=k, pad=(k - 1) // 2, res=dx_acc)
 
@@ -378,8 +394,12 @@ class Engine:
         seed_dev = None
         drop = training and not getattr(m, "disable_dropout", False)   # test hook == patching F.dropout in the reference
         if drop:
-            ops.bump_counter(self.seed_counter, self._SEED_INC)
-            seed_dev = self.seed_counter.clone()
+            if self.device_seed:                    # hipGraph capture: the counter lives on the device and is bumped by a kernel
+                ops.bump_counter(self.seed_counter, self._SEED_INC)
+                seed_dev = self.seed_counter.clone()
+            else:                                   # eager: the same stream of values, carried in the kernel arguments
+                self._seed_k += 1
+                seed_dev = (self.base_seed + self._seed_k * self._SEED_INC) & 0x7FFFFFFFFFFFFFFF
         p_enc = self.tc["encoder_dropout"] if drop else 0.0
         p_dec = self.tc["decoder_dropout"] if drop else 0.0
         p_vp = self.vp["dropout"] if drop else 0.0
@@ -475,8 +495,8 @@ class Engine:
             res = mel if i == 4 else None
             if training:
                 h_out, mean_rstd = ops.bn_train_fwd(c, P[pre + "1.weight"], P[pre + "1.bias"], self.Bf[pre + "1.running_mean"],
-                                                    self.Bf[pre + "1.running_var"], act, p_pn, _site_seed(200 + i), res=res,
-                                                    seed_dev=seed_dev)
+                                                    self.Bf[pre + "1.running_var"], act, p_pn, _seed_pair(200 + i, seed_dev)[0], res=res,
+                                                    seed_dev=_seed_pair(200 + i, seed_dev)[1])
                 self.Bf[pre + "1.num_batches_tracked"] += 1
             else:
                 mean_rstd = torch.cat([self.Bf[pre + "1.running_mean"], torch.rsqrt(self.Bf[pre + "1.running_var"] + 1e-5)])
@@ -539,7 +559,7 @@ class Engine:
             pre = f"postnet.convolutions.{i}."
             s = sv.pn[i]
             dc, dgam, dbet = ops.bn_bwd(s.c, g, s.mean_rstd, P[pre + "1.weight"], P[pre + "1.bias"], s.act, sv.p_pn,
-                                        _site_seed(200 + i), seed_dev=seed_dev)
+                                        _seed_pair(200 + i, seed_dev)[0], seed_dev=_seed_pair(200 + i, seed_dev)[1])
             G[pre + "1.weight"] += dgam
             G[pre + "1.bias"] += dbet
             self._wgrad(G[pre + "0.conv.weight"], G[pre + "0.conv.bias"], dc, s.x, T, taps=5, pad=2)
