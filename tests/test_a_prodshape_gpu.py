@@ -204,13 +204,17 @@ def test_full_size_train_step_fp32_matches_fp64_oracle_elementwise(dev, full_cas
     for a, o in zip(losses, olosses):
         assert abs(a.item() - o.item()) <= 1e-5 * max(1.0, abs(o.item()))
     assert sorted(grads) == sorted(ograds)
+    gmax = max(g.abs().max().item() for g in ograds.values())
     for n, og in ograds.items():
-        if n.endswith("w_ks.bias"):                                         # softmax is shift-invariant: true gradient 0, rounding noise
-            continue
         scale = og.abs().max().item()
         err = (grads[n] - og).abs().max().item()
-        assert err <= 2e-3 * scale + 1e-9, (n, err, scale)
-        fro = ((grads[n] - og).norm() / (og.norm() + 1e-30)).item()
+        if scale < 1e-9 * gmax:
+            # TRUE gradient zero (w_ks.bias: softmax is shift-invariant; conv biases in front of BatchNorm: the batch mean absorbs
+            # them; fp64 leaves ~1e-15): only rounding noise can be there
+            assert err <= 1e-6 * gmax, (n, err, gmax)
+            continue
+        assert err <= 2e-3 * scale, (n, err, scale)
+        fro = ((grads[n] - og).norm() / og.norm()).item()
         assert fro <= 1e-3, (n, fro)
 
 
@@ -232,16 +236,14 @@ def test_full_size_train_step_bf16_per_tensor_budget(dev, full_case):
     for a, o in zip(losses, olosses):
         assert abs(a.item() - o.item()) <= 1e-2 * max(1.0, abs(o.item())), (a.item(), o.item())
     worst = []
+    gmax = max(g.abs().max().item() for g in ograds.values())
     for n, og in ograds.items():
-        if n.endswith("w_ks.bias"):
+        if og.abs().max().item() < 1e-9 * gmax:      # true gradient zero (w_ks.bias, conv biases in front of BatchNorm): noise only
+            assert grads[n].abs().max().item() <= 1e-3 * gmax, n
             continue
-        fro = ((grads[n] - og).norm() / (og.norm() + 1e-30)).item()
+        fro = ((grads[n] - og).norm() / og.norm()).item()
         worst.append((fro, n))
         small = og.numel() <= 1024
-        # conv biases in front of BatchNorm have a TRUE gradient of zero (the batch mean absorbs them): compare absolutely
-        if "postnet" in n and n.endswith("conv.bias"):
-            assert grads[n].abs().max().item() <= 1e-2 * max(g.abs().max().item() for g in ograds.values()), n
-            continue
         assert fro <= (2e-2 if small else 1e-2), (n, fro)
     worst.sort(reverse=True)
     print("bf16 full-size per-tensor relative Frobenius error, worst 8:", [(f"{f:.2e}", n) for f, n in worst[:8]])

@@ -152,16 +152,22 @@ def test_dropout_training_runs_and_optimizer_steps(dev):
     b = synthetic_batch(52, 4, 32)
     model._ensure_flat(dev)
     opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
-    first = None
+    def probe():                                   # the objective without dropout noise (train-mode BatchNorm, no update)
+        model.disable_dropout = True
+        try:
+            return run_train(model, pcfg, mcfg, b, dev)[1][0].item()
+        finally:
+            model.disable_dropout = False
+            opt.zero_grad()
+    first = probe()
     for step in range(8):
         out, losses = run_train(model, pcfg, mcfg, b, dev)
         assert torch.isfinite(losses[0]).item()
-        if first is None:
-            first = losses[0].item()
         opt.step_and_update_lr()
         opt.zero_grad()
-    # the same fixed batch for 8 steps: loss must go down
-    assert losses[0].item() < first
+    # the same fixed batch for 8 steps: the (dropout-free) objective must go down; the dropout-on loss itself is noisier than
+    # 8 warm-up steps of learning rate ~1e-6 can move it
+    assert probe() < first
     # two forward passes in train mode differ (fresh dropout masks); eval is deterministic
     o1 = run_train(model, pcfg, mcfg, b, dev)[0][1]
     o2 = run_train(model, pcfg, mcfg, b, dev)[0][1]

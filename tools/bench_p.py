@@ -56,7 +56,8 @@ def run():
 
 def sweep():
     cfgs = [("ring/128 (P off)", {"FS2_GEMM_P": "0"}), ("persistent", {}), ("P no-MFMA", {"FS2_GEMM_ABL": "1"}),
-            ("P no-reads", {"FS2_GEMM_ABL": "2"}), ("P no-MFMA no-reads", {"FS2_GEMM_ABL": "3"}), ("P no-epilogue", {"FS2_GEMM_ABL": "4"})]
+            ("P no-reads", {"FS2_GEMM_ABL": "2"}), ("P no-MFMA no-reads", {"FS2_GEMM_ABL": "3"}), ("P no-epilogue", {"FS2_GEMM_ABL": "4"}),
+            ("P no-DMA", {"FS2_GEMM_ABL": "8"}), ("P no-DMA no-reads", {"FS2_GEMM_ABL": "10"}), ("P no-DMA no-epilogue", {"FS2_GEMM_ABL": "12"})]
     rows = {}
     for tag, env in cfgs:
         e = dict(os.environ)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2, call A: persistent kernel correctness first (short timeouts: a hang must not eat the box), A/B + ablation sweep,
 # production-shape parity suite, the whole -m gpu suite, bench line, kernel trace.
-TAG=${1:-r02a}
+TAG=${1:-r02x}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 echo "== contraction parity (persistent kernel)"; ( time timeout 420 python -m pytest tests/test_a_prodshape_gpu.py -x -q -k contraction ) > gpurun_out/${TAG}_pytest_contraction.log 2>&1; tail -5 gpurun_out/${TAG}_pytest_contraction.log
