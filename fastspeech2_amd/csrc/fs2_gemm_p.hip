@@ -336,7 +336,7 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
 #define FS2P_MFMA(SET, MB, NB, AV)                                                                                          \
     if (!(ABL & 1)) acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bf[SET][NB]),        \
                                                                        __builtin_bit_cast(bf16x8, AV), acc[MB][NB], 0, 0, 0)
-#define FS2P_SLICE(SET, MASKED, LIVE0, LIVE1, DO_READS, JN, ABASE, AKEY, BBASE)                                             \
+#define FS2P_SLICE(SET, MASKED, LIVE0, LIVE1, DO_READS, JN, ABASE, AKEY, BBASE, HOOK_A, HOOK_B)                             \
     do {                                                                                                                    \
         u32x4 av0, av1;                                                                                                     \
         FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
@@ -358,9 +358,11 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         av1 = Af[SET][1]; if (MASKED && !(LIVE1)) av1 = u32x4{0u, 0u, 0u, 0u};                                              \
         FS2P_MFMA(SET, 1, 0, av1); FS2P_FENCE();                                                                            \
         if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][3], ba_, 12288); } FS2P_FENCE();                                           \
+        HOOK_A; FS2P_FENCE();                                 /* every read of THIS slice's operands has landed here */     \
         FS2P_MFMA(SET, 1, 1, av1); FS2P_FENCE();                                                                            \
         if (DO_READS) { FS2P_DS_READ(Af[SET ^ 1][1], aa_, 4096); } FS2P_FENCE();                                            \
         FS2P_MFMA(SET, 1, 2, av1); FS2P_FENCE();                                                                            \
+        HOOK_B; FS2P_FENCE();                                                                                               \
         FS2P_MFMA(SET, 1, 3, av1); FS2P_FENCE();                                                                            \
     } while (0)
 
@@ -371,6 +373,7 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         reinterpret_cast<volatile unsigned*>(smem + C::AUX + P_FLAGS_OFF)[threadIdx.x] = 0u;
     FS2P_WAIT_LGKM(0);                                       // kernel arguments, lens staging, counters: lgkmcnt is ours from here
     __builtin_amdgcn_s_barrier();                            // the ONE barrier of the kernel: lengths staged, counters zeroed
+    __builtin_amdgcn_s_setprio(1);                           // the SIMD's other wave is a loader that mostly polls: MFMA issue first
     p_wait_prog(prog_l4, 1u);                                // step 0 has landed
     if (!(ABL & 2)) {
         const unsigned aa = a_base(0, 0) + (a_key(0) << 4), ba = b_base(0) + (ckb << 4);
@@ -420,21 +423,23 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
                     const bool live0 = (vmask[0] >> tap) & 1u, live1 = (vmask[1] >> tap) & 1u;
                     const bool more = gs + 1 < total;                       // another step follows (this tile or the next)
                     const unsigned ab = a_base(abuf, tap), ak = a_key(tap), bb = b_base(slot);
-                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 1, ab, ak, bb);
-                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 2, ab, ak, bb);
-                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 3, ab, ak, bb);
-                    u32x4 pl;                                               // the loaders' progress, read in front of the wait below
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(pl) : "v"(prog_l4));
-                    FS2P_WAIT_LGKM(0); FS2P_FENCE();                        // every read of slot(gs) / its halo tile has landed
                     const bool last_of_tile = (kc == nkc - 1) && (tap == taps - 1);
-                    // slot(gs) is released to the loaders - except after a tile's last step: its activation buffer becomes the
-                    // epilogue's staging patch and is released when the tile has been stored
-                    if (!last_of_tile) p_write_prog(prog_c, (unsigned)(gs + 1));
-                    else p_write_prog(prog_r + wm * 4, (unsigned)(k + 1));      // my reads of this tile's operands are over
-                    if (more) {                                             // step gs+1 landed?  (almost always: the loaders run ahead)
-                        const unsigned have = (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(pl[0], pl[1]), min(pl[2], pl[3])));
-                        if (have < (unsigned)(gs + 2)) p_wait_prog(prog_l4, (unsigned)(gs + 2));
-                    }
+                    // The step boundary carries NO lgkmcnt(0): a lone wave per SIMD cannot hide a stall, every full drain of the
+                    // LDS queue is ~200-500 idle MFMA cycles (r02b: consumer alone 203 us against ~105 us of MFMA work).  So
+                    //   * the loaders' progress is read one slice EARLY (behind MFMA 6 of slice 1) and looked at in slice 2,
+                    //     where it has long returned (lgkmcnt is in order: one counted wait covers it);
+                    //   * "step gs is read" is published LATE, from inside slice 3 at the point where the counted waits have
+                    //     already established that slice 3's own operands - the step's last reads - have landed.
+                    u32x4 pl;
+                    unsigned have = 0xffffffffu;
+                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 1, ab, ak, bb, (void)0, (void)0);
+                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 2, ab, ak, bb, (void)0,
+                               asm volatile("ds_read_b128 %0, %1" : "=v"(pl) : "v"(prog_l4)));
+                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 3, ab, ak, bb,
+                               FS2P_WAIT_LGKM(4),            /* the progress read (older than the 4-5 fragment reads behind it) is back */
+                               have = (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(pl[0], pl[1]), min(pl[2], pl[3]))));
+                    // step gs+1 landed?  (almost always: the loaders run D-1 steps ahead) - otherwise poll with full waits
+                    if (more && have < (unsigned)(gs + 2)) p_wait_prog(prog_l4, (unsigned)(gs + 2));
                     FS2P_FENCE();
                     int nslot = slot + 1; if (nslot == D) nslot = 0;
                     int ntap = tap + 1, ngc = gc; if (ntap == taps) { ntap = 0; ++ngc; }
@@ -443,7 +448,11 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
                     // (after the workgroup's very last step these six reads fetch operands nobody uses: issuing them unconditionally keeps the
                     // fragment registers single-definition - a conditional read would make the compiler merge two register sets with
                     // copies, and a copy of a register with a read in flight carries stale data)
-                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 0, nab, nak, nbb);
+                    // HOOK_A of this slice: slot(gs) is released to the loaders - except after a tile's last step: its activation
+                    // buffer becomes the epilogue's staging patch and is released when the tile has been stored
+                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 0, nab, nak, nbb,
+                               p_write_prog(last_of_tile ? prog_r + wm * 4 : prog_c, last_of_tile ? (unsigned)(k + 1) : (unsigned)(gs + 1)),
+                               (void)0);
                     ++gs; slot = nslot; gc = ngc;
                 }
             }
