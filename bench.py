@@ -248,7 +248,7 @@ def synth_main(args):
     if rank == 0 and not args.no_roofline:
         # instrumented replay: HIP events around every conv_gemm launch of the acoustic model + vocoder (one stream)
         from fastspeech2_amd import ops
-        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel", 5: "conv_gemm_p_kernel"}
+        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel", 5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)"}
         ops.PROFILE = {}
         for _ in range(2):
             step()
@@ -447,7 +447,7 @@ def main():
         rec = prof.get("conv_gemm", [])
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel",
-                 5: "conv_gemm_p_kernel"}
+                 5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)"}
         # fraction of the padded rows that are valid, per sequence length (launches that pass `lens` skip fully padded tiles:
         # `achieved` counts the reference's padded algorithmic FLOPs, `achieved_valid_rows` only those of valid rows)
         vfrac = {int(b["max_mel_len"]): float(b["mel_lens"].sum()) / (args.batch * b["max_mel_len"]),
@@ -468,7 +468,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": names.get(dom, str(dom)) + " (%s)" % args.dtype,
                         "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "achieved_valid_rows": round(flv / (ms * 1e-3) / 1e12, 1), "frac_valid_rows": round(flv / (ms * 1e-3) / 1e12 / peak, 4),
-                        "traffic": (pmc_traffic(names.get(dom, "conv_gemm")) if (args.dtype == "bf16" and args.workload == "ljspeech" and args.dec_layers == 4
+                        "traffic": (pmc_traffic(names.get(dom, "conv_gemm").split(" ")[0]) if (args.dtype == "bf16" and args.workload == "ljspeech" and args.dec_layers == 4
                                                                                     and not args.frame_level and args.batch == 48) else None),   # PMC passes exist for the reported config only
                         "launches_per_step": n // 3, "kernel_ms_per_step": round(ms / 3, 3), "avg_launch_us": round(ms / n * 1e3, 1),
                         "gflop_per_launch": round(fl / n / 1e9, 1),

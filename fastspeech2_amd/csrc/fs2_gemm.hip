@@ -969,7 +969,7 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map) {
     // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
     static const int ksplit_on = fs2_dev_env("FS2_GEMM_KSPLIT", 1);
     p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= 32;
-    p.variant = skinny ? FS2_GEMM_SKINNY : (persist ? FS2_GEMM_PERSIST : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN)));
+    p.variant = skinny ? FS2_GEMM_SKINNY : (persist ? (taps == 1 ? FS2_GEMM_PERSIST_1TAP : FS2_GEMM_PERSIST) : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN)));
     return p;
 }
 
@@ -1017,7 +1017,7 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
         if (Cin == 32) launch_skinny<32>(a, stream);
         else if (Cin == 64) launch_skinny<64>(a, stream);
         else launch_skinny<128>(a, stream);
-    } else if (pk.variant == FS2_GEMM_PERSIST) {
+    } else if (pk.variant == FS2_GEMM_PERSIST || pk.variant == FS2_GEMM_PERSIST_1TAP) {
         static const int abl = fs2_dev_env("FS2_GEMM_ABL", 0);
         fs2_conv_gemm_p_launch(a, tile_map, stream, abl);
     } else if (pk.variant == FS2_GEMM_RING) {

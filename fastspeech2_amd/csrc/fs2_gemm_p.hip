@@ -18,18 +18,20 @@
 //   * fully padded M-tiles (rows t >= lens[b]) are known before the launch (fs2_tile_map): the real tiles are dealt
 //     round-robin to the workgroups (M-fastest: neighbours share the weight slice), the padded ones are zero-filled by
 //     the consumer waves while the first operands are in flight.
-// Synchronisation (r02b): NO per-step workgroup barrier.  A rendezvous every 64-deep K-step made each step cost the MAXIMUM of
-// the loader's and the consumer's time (r02a ablation, k=9 FFN conv: loader skeleton alone 97 us, MFMA-only consumer + loader
-// 150 us, everything 215 us; ring depth cannot absorb jitter when every wave must arrive at every barrier).  Producer and
-// consumer waves now exchange PROGRESS COUNTERS in LDS: loader wave l publishes prog_l[l] = s+1 once its DMA of step s has
-// landed (counted vmcnt, then a ds_write); consumer wave w publishes prog_c[w] = s+1 once its last fragment read of step s has
-// landed.  A consumer reads the four loader counters with ONE broadcast ds_read_b128 that rides in front of the lgkmcnt(0) it
-// needs anyway, a loader polls the four consumer counters (s_sleep between polls) before it overwrites a slot - so a wave
-// only ever waits when the data it needs is really missing, and the ring's D-1 slots of run-ahead are real.
-// Epilogue (r02b): the register epilogue of r02a stored 32-byte pieces of 32 different rows per instruction (the accumulator
-// layout makes a LANE a row): 25 of 215 us, and half of the short-K launches.  The tile now goes through an 8 KB per-wave
-// f32 staging patch and leaves as full 128-byte row segments; the patch is the activation buffer of the tile's LAST step,
-// which the wave keeps (it withholds its progress counter) until its stores are issued - no extra LDS.
+// Two redesigns were measured against this version in round 2 and NOT kept (git history: "persistent kernel v2" / "v3"):
+//   * progress counters in LDS instead of the per-step barrier (loaders publish "step s landed", consumers "step s read", a
+//     wave only waits when its data is missing) + an LDS-staged full-line epilogue: correct, but SLOWER at every shape (k=9 FFN
+//     conv 247 vs 215 us, QKV 62 vs 52 us): with ONE consumer wave per SIMD every counter read/publish sits in the MFMA issue
+//     stream, and the consumer alone (no DMA at all) already needs 203 us for ~105 us of MFMA work - the lone wave's in-order
+//     issue of reads + MFMAs is the limiter, not the rendezvous;
+//   * the same without any lgkmcnt(0) at the step boundary (counter read one slice early, release published from inside the
+//     next slice): no faster (253 us), and it exposed how fragile asm-tracked LDS reads are across code the compiler may
+//     re-register (stale copies of in-flight fragments at tile boundaries).
+// Ablations of THIS version (profiles/r02a_bench_p.md, k=9 FFN conv, 215 us): loaders + barriers alone 97 us, + MFMAs 150 us,
+// + fragment reads 215 us; epilogue 25 us of it.
+// Synchronisation: one raw s_barrier per K-step (64 deep) publishes the slot the loaders filled D-1 steps earlier and
+// releases the slot the consumers just left; LDS-DMA is issued from inline asm and tracked with counted vmcnt
+// (loaders), fragment reads with counted lgkmcnt (consumers) - see fs2_gemm.hip for why the compiler cannot do either.
 #include "fs2_gemm.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -47,11 +49,7 @@ template <> struct PCfg<true> {
     static constexpr int AUX = B_OFF + D * 16384;
 };
 static constexpr int P_MAXB = 1024;                       // lens[] staged in LDS
-static constexpr int P_FLAGS_OFF = P_MAXB * 4 + 4 * 512;   // prog_l[4] | prog_c[4] (u32 each)
-static constexpr int P_AUX_BYTES = P_FLAGS_OFF + 48;       // lens + one 128-float bias line per consumer wave + progress counters
-// (third counter set prog_r[4]: tiles whose LAST step a consumer wave has finished reading - the neighbour handshake of the
-//  staged epilogue, see p_consumer)
-static constexpr unsigned P_SPIN_CAP = 1u << 22;           // hang guard of the progress-counter polls (~1 s): fall through, tests fail
+static constexpr int P_AUX_BYTES = P_MAXB * 4 + 4 * 512;  // lens + one 128-float bias line per consumer wave
 static constexpr int P_B_BYTES = 128 * 128;
 
 struct PSched {
@@ -69,36 +67,8 @@ __device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_li
     mt = s.tmap ? (int)__builtin_amdgcn_readlane(mt_list, k) : mi;
 }
 
-// progress counters: all four of a side in one broadcast ds_read_b128 (every lane the same address); min over the four
-__device__ __forceinline__ unsigned p_read_prog(unsigned lds_addr4) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr4) : "memory");
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(v[0], v[1]), min(v[2], v[3])));
-}
-__device__ __forceinline__ void p_write_prog(unsigned lds_addr, unsigned val) {
-    // ONE lane stores (64 lanes storing to one address would be serialised by the LDS); exec is narrowed inside the asm so
-    // that no branch splits the consumer's pinned instruction stream
-    unsigned long long saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved) : "v"(lds_addr), "v"(val) : "memory");
-}
-__device__ __forceinline__ void p_wait_one(unsigned lds_addr, unsigned need) {
-    for (unsigned spins = 0; spins < P_SPIN_CAP; ++spins) {
-        unsigned v;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr) : "memory");
-        if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= need) return;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-__device__ __forceinline__ void p_wait_prog(unsigned lds_addr4, unsigned need) {
-    for (unsigned spins = 0; spins < P_SPIN_CAP; ++spins) {
-        if (p_read_prog(lds_addr4) >= need) return;
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ loader waves
-template <bool ONE_TAP, int ABL>
+template <bool ONE_TAP>
 __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int lw,
                                          unsigned mt_list, int ntiles) {
     typedef PCfg<ONE_TAP> C;
@@ -149,7 +119,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
             const unsigned d = (ldsA[j] == 0xffffffffu) ? smem_base + C::SCRATCH : smem_base + buf_or_slot * C::A_BYTES + ldsA[j];
-            if (!(ABL & 8)) glds16_sbase(offA[j], base, __builtin_amdgcn_readfirstlane(d));
+            glds16_sbase(offA[j], base, __builtin_amdgcn_readfirstlane(d));
         }
     };
     auto issue_step = [&]() {                                // operands of global step `is` -> slot `islot`
@@ -158,21 +128,19 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
         const unsigned char* base = Wb + ((size_t)itap * a.Cin + (size_t)ikc * 64) * 2;
         const unsigned d0 = smem_base + C::B_OFF + islot * P_B_BYTES + lw * 4096;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (!(ABL & 8)) glds16_sbase(offB[j], base, d0 + j * 1024);
+        for (int j = 0; j < 4; ++j) glds16_sbase(offB[j], base, d0 + j * 1024);
     };
     auto advance_issue = [&]() {
         ++is;
         if (++itap == taps) { itap = 0; if (++ikc == nkc) { ikc = 0; ++ik; } }
         if (++islot == D) islot = 0;
     };
-    const unsigned prog_l = smem_base + C::AUX + P_FLAGS_OFF + lw * 4, prog_c4 = smem_base + C::AUX + P_FLAGS_OFF + 16;
     if (!ONE_TAP) issue_A(0, 0, 0);
 #pragma unroll
     for (int p = 0; p < D - 1; ++p) {
         if (is < total) issue_step();
         advance_issue();
     }
-    __builtin_amdgcn_s_barrier();                            // the ONE barrier of the kernel: progress counters are zeroed
     // ---- consume side
     int ck = 0, ckc = 0, ctap = 0, gc = 0;                   // tile / chunk / tap of the step being published; global chunk
     for (int cs = 0; cs < total; ++cs) {
@@ -186,12 +154,8 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
             if (a_young) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");         // (D-2) x 4 B + 9 A, D = 5
             else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         }
-        p_write_prog(prog_l, (unsigned)(cs + 1));           // my part of step cs is in LDS
-        const bool issue_a = !ONE_TAP && ctap == 0 && gc + 1 < nchunks;
-        // slot (cs-1) % D (step cs + D - 1 goes there) and halo buffer (gc+1) & 1 are free once every consumer wave has
-        // finished step cs - 1
-        if (cs > 0 && (issue_a || is < total)) p_wait_prog(prog_c4, (unsigned)cs);
-        if (issue_a) {
+        __builtin_amdgcn_s_barrier();                        // publishes slot(cs); the consumers have left slot(cs-1)
+        if (!ONE_TAP && ctap == 0 && gc + 1 < nchunks) {
             int nk = ck, nkc_ = ckc + 1;
             if (nkc_ == nkc) { nkc_ = 0; ++nk; }
             issue_A(nk, nkc_, (gc + 1) & 1);
@@ -207,20 +171,15 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
 #define FS2P_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory")
 #define FS2P_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// Epilogue.  The accumulators are TRANSPOSED: lane (fl, fh) holds, for row m = mbase + fl, the columns
-// nb*32 + 8*g + 4*fh + e (g = r>>2, e = r&3).  v_permlane32_swap pairs (g, g+1) across the two half-waves, so a lane ends up with
-// columns nb*32 + fh*8 + [0,8) and nb*32 + 16 + fh*8 + [0,8).  Stored from there a wave instruction would touch 32 rows x 32
-// bytes; instead each 32-row x 64-column piece goes through the wave's private f32 staging patch (256-byte rows, 16-byte
-// chunk c of row r kept at chunk c ^ (r & 15): conflict-free for the row-per-lane writes and the row-contiguous reads) and
-// is read back with 8 consecutive lanes covering 128 output bytes of ONE row: bias / activation / residual / gate / scale /
-// padded-row zero / accumulate run in that layout (the residual and accumulate operands are read as full lines too).
+// epilogue straight from the transposed accumulators: lane (fl, fh) holds, for row m = mbase + fl, the columns
+// nb*32 + 8*g + 4*fh + e (g = r>>2, e = r&3).  v_permlane32_swap pairs (g, g+1) across the two half-waves so that a lane ends
+// up with columns nb*32 + fh*8 + [0,8) (from g = 0,1) and nb*32 + 16 + fh*8 + [0,8) (from g = 2,3): two 16-byte bf16 runs.
 template <int ACT>
-__device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][4], int m0, int n0, int wm, int lane,
-                                           float* stage, const int32_t* lens_s, float* bias_s) {
+__device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][4], int m0, int n0, int wm, int fl, int fh,
+                                           const int32_t* lens_s, float* bias_s, int lane) {
     bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
     const bf16_t* R = reinterpret_cast<const bf16_t*>(a.R);
     const bool gate = a.act == FS2_ACT_GATE;
-    const int fl = lane & 31, fh = lane >> 5;
     // bias line of this tile -> this wave's private LDS line (same wave writes and reads: LDS ops are in order)
     if (a.bias) {
         if (lane < 32) {
@@ -231,50 +190,42 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
             *reinterpret_cast<float4*>(bias_s + lane * 4) = bv;
         }
     }
-    const int rr = lane >> 3, pp = lane & 7;                 // read-back: row rr + 8 i, 16-byte bf16 output chunk pp (8 columns)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + wm * 64 + mb * 32 + fl;
+        const bool rowok = m < a.M;
+        bool padrow = false;
+        if (a.lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
+        bf16_t* yrow = Y + (size_t)m * a.ldy;
+        const bf16_t* rrow = R ? R + (size_t)m * a.ldr : nullptr;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int nb = 0; nb < 4; ++nb) {
+            float c[2][8];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int nb = 2 * q + t;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][e]), __float_as_uint(acc[mb][nb][4 + e]), false, false);
-                    u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][8 + e]), __float_as_uint(acc[mb][nb][12 + e]), false, false);
-                    acc[mb][nb][e] = __uint_as_float(s0[0]); acc[mb][nb][4 + e] = __uint_as_float(s0[1]);
-                    acc[mb][nb][8 + e] = __uint_as_float(s1[0]); acc[mb][nb][12 + e] = __uint_as_float(s1[1]);
-                }
-                // regs [0,8) = columns t*32 + fh*8 + [0,8), regs [8,16) = columns t*32 + 16 + fh*8 + [0,8) of the 64-column piece
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int cc = t * 8 + (h >> 1) * 4 + fh * 2 + (h & 1);          // 16-byte (4-column) chunk of the 256-byte row
-                    *reinterpret_cast<float4*>(stage + fl * 64 + ((cc ^ (fl & 15)) << 2)) =
-                        make_float4(acc[mb][nb][4 * h], acc[mb][nb][4 * h + 1], acc[mb][nb][4 * h + 2], acc[mb][nb][4 * h + 3]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][e]), __float_as_uint(acc[mb][nb][4 + e]), false, false);
+                u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][8 + e]), __float_as_uint(acc[mb][nb][12 + e]), false, false);
+                c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
+                c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = rr + 8 * i;
-                const float4 x0 = *reinterpret_cast<const float4*>(stage + r * 64 + (((2 * pp) ^ (r & 15)) << 2));
-                const float4 x1 = *reinterpret_cast<const float4*>(stage + r * 64 + (((2 * pp + 1) ^ (r & 15)) << 2));
-                const int m = m0 + wm * 64 + mb * 32 + r;
-                const int nl = q * 64 + pp * 8, n = n0 + nl;
-                if (m >= a.M || n >= a.N) continue;          // N % 8 == 0: a chunk is inside or outside
-                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            for (int ch = 0; ch < 2; ++ch) {
+                const int nl = nb * 32 + ch * 16 + fh * 8;
+                const int n = n0 + nl;
+                if (!rowok || n >= a.N) continue;            // N % 8 == 0: a chunk is inside or outside
+                float v[8];
                 if (a.bias) {
                     const float4 b0 = *reinterpret_cast<const float4*>(bias_s + nl), b1 = *reinterpret_cast<const float4*>(bias_s + nl + 4);
                     const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bb[e];
-                }
+                    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(c[ch][e] + bb[e], a.slope);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(v[e], a.slope);
-                bf16_t* yp = Y + (size_t)m * a.ldy + n;
-                if (R) {
-                    const uint4 rv = *reinterpret_cast<const uint4*>(R + (size_t)m * a.ldr + n);
-                    const uint32_t* u = reinterpret_cast<const uint32_t*>(&rv);
+                    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(c[ch][e], a.slope);
+                }
+                if (rrow) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(rrow + n);
+                    const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
@@ -282,12 +233,10 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
                         v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
                     }
                 }
-                bool padrow = false;
-                if (a.lens) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { v[e] *= a.out_scale; if (padrow) v[e] = 0.f; }
                 if (a.accumulate) {
-                    const uint4 yy = *reinterpret_cast<const uint4*>(yp);
+                    const uint4 yy = *reinterpret_cast<const uint4*>(yrow + n);
                     const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
@@ -296,13 +245,13 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
                 uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<uint4*>(yp) = o;
+                *reinterpret_cast<uint4*>(yrow + n) = o;
             }
         }
     }
 }
 
-// ABL (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue, 8 = loaders issue no DMA
+// ABL (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue
 template <bool ONE_TAP, int ABL>
 __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int wm,
                                            unsigned mt_list, int ntiles, const int32_t* lens_s, float* bias_s) {
@@ -336,7 +285,7 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
 #define FS2P_MFMA(SET, MB, NB, AV)                                                                                          \
     if (!(ABL & 1)) acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bf[SET][NB]),        \
                                                                        __builtin_bit_cast(bf16x8, AV), acc[MB][NB], 0, 0, 0)
-#define FS2P_SLICE(SET, MASKED, LIVE0, LIVE1, DO_READS, JN, ABASE, AKEY, BBASE, HOOK_A, HOOK_B)                             \
+#define FS2P_SLICE(SET, MASKED, LIVE0, LIVE1, DO_READS, JN, ABASE, AKEY, BBASE)                                             \
     do {                                                                                                                    \
         u32x4 av0, av1;                                                                                                     \
         FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
@@ -358,23 +307,15 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         av1 = Af[SET][1]; if (MASKED && !(LIVE1)) av1 = u32x4{0u, 0u, 0u, 0u};                                              \
         FS2P_MFMA(SET, 1, 0, av1); FS2P_FENCE();                                                                            \
         if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][3], ba_, 12288); } FS2P_FENCE();                                           \
-        HOOK_A; FS2P_FENCE();                                 /* every read of THIS slice's operands has landed here */     \
         FS2P_MFMA(SET, 1, 1, av1); FS2P_FENCE();                                                                            \
         if (DO_READS) { FS2P_DS_READ(Af[SET ^ 1][1], aa_, 4096); } FS2P_FENCE();                                            \
         FS2P_MFMA(SET, 1, 2, av1); FS2P_FENCE();                                                                            \
-        HOOK_B; FS2P_FENCE();                                                                                               \
         FS2P_MFMA(SET, 1, 3, av1); FS2P_FENCE();                                                                            \
     } while (0)
 
     int gs = 0, gc = 0, slot = 0;                            // global step / chunk, ring slot of step gs
-    const unsigned prog_l4 = smem_u + C::AUX + P_FLAGS_OFF, prog_c = smem_u + C::AUX + P_FLAGS_OFF + 16 + wm * 4;
-    const unsigned prog_r = smem_u + C::AUX + P_FLAGS_OFF + 32;
-    if (threadIdx.x < 12)                                    // (plain store: p_write_prog writes from lane 0 only)
-        reinterpret_cast<volatile unsigned*>(smem + C::AUX + P_FLAGS_OFF)[threadIdx.x] = 0u;
-    FS2P_WAIT_LGKM(0);                                       // kernel arguments, lens staging, counters: lgkmcnt is ours from here
-    __builtin_amdgcn_s_barrier();                            // the ONE barrier of the kernel: lengths staged, counters zeroed
-    __builtin_amdgcn_s_setprio(1);                           // the SIMD's other wave is a loader that mostly polls: MFMA issue first
-    p_wait_prog(prog_l4, 1u);                                // step 0 has landed
+    FS2P_WAIT_LGKM(0);                                       // kernel arguments, lens staging: lgkmcnt is ours from here
+    __builtin_amdgcn_s_barrier();                            // slot(0) published
     if (!(ABL & 2)) {
         const unsigned aa = a_base(0, 0) + (a_key(0) << 4), ba = b_base(0) + (ckb << 4);
         FS2P_DS_READ(Af[0][0], aa, 0); FS2P_DS_READ(Bf[0][0], ba, 0); FS2P_DS_READ(Bf[0][1], ba, 4096);
@@ -423,23 +364,11 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
                     const bool live0 = (vmask[0] >> tap) & 1u, live1 = (vmask[1] >> tap) & 1u;
                     const bool more = gs + 1 < total;                       // another step follows (this tile or the next)
                     const unsigned ab = a_base(abuf, tap), ak = a_key(tap), bb = b_base(slot);
-                    const bool last_of_tile = (kc == nkc - 1) && (tap == taps - 1);
-                    // The step boundary carries NO lgkmcnt(0): a lone wave per SIMD cannot hide a stall, every full drain of the
-                    // LDS queue is ~200-500 idle MFMA cycles (r02b: consumer alone 203 us against ~105 us of MFMA work).  So
-                    //   * the loaders' progress is read one slice EARLY (behind MFMA 6 of slice 1) and looked at in slice 2,
-                    //     where it has long returned (lgkmcnt is in order: one counted wait covers it);
-                    //   * "step gs is read" is published LATE, from inside slice 3 at the point where the counted waits have
-                    //     already established that slice 3's own operands - the step's last reads - have landed.
-                    u32x4 pl;
-                    unsigned have = 0xffffffffu;
-                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 1, ab, ak, bb, (void)0, (void)0);
-                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 2, ab, ak, bb, (void)0,
-                               asm volatile("ds_read_b128 %0, %1" : "=v"(pl) : "v"(prog_l4)));
-                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 3, ab, ak, bb,
-                               FS2P_WAIT_LGKM(4),            /* the progress read (older than the 4-5 fragment reads behind it) is back */
-                               have = (unsigned)__builtin_amdgcn_readfirstlane((int)min(min(pl[0], pl[1]), min(pl[2], pl[3]))));
-                    // step gs+1 landed?  (almost always: the loaders run D-1 steps ahead) - otherwise poll with full waits
-                    if (more && have < (unsigned)(gs + 2)) p_wait_prog(prog_l4, (unsigned)(gs + 2));
+                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 1, ab, ak, bb);
+                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 2, ab, ak, bb);
+                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 3, ab, ak, bb);
+                    FS2P_WAIT_LGKM(0); FS2P_FENCE();                        // every read of slot(gs) / its halo tile has landed
+                    if (more) __builtin_amdgcn_s_barrier();                 // slot(gs+1) published, slot(gs) released
                     FS2P_FENCE();
                     int nslot = slot + 1; if (nslot == D) nslot = 0;
                     int ntap = tap + 1, ngc = gc; if (ntap == taps) { ntap = 0; ++ngc; }
@@ -448,11 +377,7 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
                     // (after the workgroup's very last step these six reads fetch operands nobody uses: issuing them unconditionally keeps the
                     // fragment registers single-definition - a conditional read would make the compiler merge two register sets with
                     // copies, and a copy of a register with a read in flight carries stale data)
-                    // HOOK_A of this slice: slot(gs) is released to the loaders - except after a tile's last step: its activation
-                    // buffer becomes the epilogue's staging patch and is released when the tile has been stored
-                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 0, nab, nak, nbb,
-                               p_write_prog(last_of_tile ? prog_r + wm * 4 : prog_c, last_of_tile ? (unsigned)(k + 1) : (unsigned)(gs + 1)),
-                               (void)0);
+                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 0, nab, nak, nbb);
                     ++gs; slot = nslot; gc = ngc;
                 }
             }
@@ -460,14 +385,8 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         if (need_mask) run_tile(std::true_type{}); else run_tile(std::false_type{});
         if (k + 1 == ntiles) FS2P_WAIT_LGKM(0);               // the dangling prefetch of the last step
 
-        // staging patch: this wave's 8 KB of the activation buffer the tile's last step read (slot for taps == 1, halo buffer else)
-        const int last_abuf = ONE_TAP ? (slot == 0 ? D - 1 : slot - 1) : ((gc - 1) & 1);
-        float* stage = reinterpret_cast<float*>(smem + last_abuf * C::A_BYTES + wm * 8192);
-        // the patch is rows [64 wm, 64 wm + 64) of that buffer: mine alone for taps == 1; with taps the wave BELOW me read its
-        // halo (up to 16 rows) out of my first rows during the last step - wait until it has finished that step
-        if (!ONE_TAP && wm > 0) p_wait_one(prog_r + (wm - 1) * 4, (unsigned)(k + 1));
         if (!(ABL & 4)) {
-            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wm, lane, stage, lens_s, bias_s)));
+            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wm, fl, fh, lens_s, bias_s, lane)));
         } else {
             float s = 0.f;
 #pragma unroll
@@ -477,9 +396,6 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
             if (s == 12345.678f) reinterpret_cast<bf16_t*>(a.Y)[0] = 0;
         }
         if (ABL & 2) asm volatile("" :: "v"(Af[0][0]), "v"(Bf[0][0]));
-        // the staging reads have returned (the stores consumed them): hand the tile's last slot / halo buffer to the loaders
-        FS2P_WAIT_LGKM(0);
-        p_write_prog(prog_c, (unsigned)gs);
     }
 #undef FS2P_SLICE
 #undef FS2P_MFMA
@@ -530,10 +446,12 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
                 }
             }
         }
-        // (the staged lengths become visible to the other consumer waves at the kernel's one barrier, inside p_consumer)
+        // the four consumer waves make the staged lengths visible to each other before anyone's epilogue: they all pass
+        // the per-step barriers (>= 1) before the first epilogue, and LDS writes are ordered ahead of the wave's barrier
+        // arrival by the s_waitcnt lgkmcnt(0) in front of the first barrier.
         if (ntiles > 0) p_consumer<ONE_TAP, ABL>(a, sc, smem, lane, wave, load_mt_list(), ntiles, lens_s, bias_s);
     } else if (ntiles > 0) {                                 // (a workgroup without real tiles runs no barrier on either side)
-        p_loader<ONE_TAP, ABL>(a, sc, smem, lane, wave - 4, load_mt_list(), ntiles);
+        p_loader<ONE_TAP>(a, sc, smem, lane, wave - 4, load_mt_list(), ntiles);
     }
 }
 
@@ -627,9 +545,6 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
         case 2: if (taps == 1) launch_p<true, 2>(a, sc, stream); else launch_p<false, 2>(a, sc, stream); return;
         case 3: if (taps == 1) launch_p<true, 3>(a, sc, stream); else launch_p<false, 3>(a, sc, stream); return;
         case 4: if (taps == 1) launch_p<true, 4>(a, sc, stream); else launch_p<false, 4>(a, sc, stream); return;
-        case 8: if (taps == 1) launch_p<true, 8>(a, sc, stream); else launch_p<false, 8>(a, sc, stream); return;
-        case 10: if (taps == 1) launch_p<true, 10>(a, sc, stream); else launch_p<false, 10>(a, sc, stream); return;
-        case 12: if (taps == 1) launch_p<true, 12>(a, sc, stream); else launch_p<false, 12>(a, sc, stream); return;
         default: break;
     }
 #endif

@@ -58,7 +58,8 @@ int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, fs2_
 #define FS2_GEMM_DMA 2     /* conv_gemm_dma_kernel: 128x128 LDS-DMA, halo reuse (incl. in-workgroup split-K) */
 #define FS2_GEMM_RING 3    /* conv_gemm_ring_kernel: 256x128 wave-specialised */
 #define FS2_GEMM_SKINNY 4  /* conv_skinny_kernel: C = 32 / 64 */
-#define FS2_GEMM_PERSIST 5 /* conv_gemm_p_kernel: persistent 256x128, 64x128 consumer wave tiles, register epilogue */
+#define FS2_GEMM_PERSIST 5 /* conv_gemm_p_kernel<false>: persistent 256x128 convolution (taps >= 3), MFMA-bound */
+#define FS2_GEMM_PERSIST_1TAP 6 /* conv_gemm_p_kernel<true>: the same kernel for taps == 1 (Linear / k=1 conv): HBM-bound at K <= 1024 */
 int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens, int has_map, int M, int N, int Cin, int S, int taps,
                           int dil, int in_act, float in_slope, int dtype);
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
