@@ -57,13 +57,39 @@ struct PSched {
     int ntm, ntn;              // M-tiles (real + padded), N-tiles
     int n_real, n_pad;         // real / padded M-tiles (read from the tile map on the device)
     const int32_t* tmap;       // [0] = n_real, [1 .. ntm] = real M-tiles then padded M-tiles; null = identity (no lens)
+    int order;                 // 0: M-fastest over all workgroups (neighbours share the weight slice - convolutions, whose
+                               //    weights exceed an XCD's L2 when every N-tile is live at once);
+                               // 1: per XCD, N-fastest: the G/8 workgroups the dispatcher places on one XCD (b % 8) walk ALL
+                               //    N-tiles of the same M-tile together, so the activation tile is fetched into that XCD's L2
+                               //    once instead of once per N-tile (taps == 1 with small weights: QKV re-read its input 6x)
 };
+
+// index (into the real-M-tile list) and N-tile of the k-th tile of workgroup s.b; false when the workgroup has no k-th tile
+__device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt) {
+    if (s.order == 0) {
+        const int u = s.b + k * s.G;
+        if (u >= s.n_real * s.ntn) return false;
+        nt = u / s.n_real;
+        mi = u - nt * s.n_real;
+        return true;
+    }
+    const int x = s.b & 7, j = s.b >> 3, pos = k * (s.G >> 3) + j;
+    const int mil = pos / s.ntn;
+    nt = pos - mil * s.ntn;
+    mi = x + 8 * mil;
+    return mi < s.n_real;
+}
+__device__ __forceinline__ int p_ntiles(const PSched& s) {
+    if (s.order == 0) return (s.n_real * s.ntn - s.b + s.G - 1) / s.G;
+    const int x = s.b & 7, j = s.b >> 3, g8 = s.G >> 3;
+    const int nx = s.n_real > x ? (s.n_real - x + 7) >> 3 : 0;
+    return (nx * s.ntn - j + g8 - 1) / g8;
+}
 
 // k-th tile of this workgroup -> (M-tile, N-tile); the M-tile ids of a workgroup's first 64 tiles sit in `mt_list` (lane k)
 __device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_list, int& mt, int& nt) {
-    const int u = s.b + k * s.G;
-    nt = u / s.n_real;
-    const int mi = u - nt * s.n_real;
+    int mi;
+    (void)p_unit(s, k, mi, nt);
     mt = s.tmap ? (int)__builtin_amdgcn_readlane(mt_list, k) : mi;
 }
 
@@ -415,15 +441,14 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
     }
     int32_t* lens_s = reinterpret_cast<int32_t*>(smem + C::AUX);
     float* bias_s = reinterpret_cast<float*>(smem + C::AUX + P_MAXB * 4) + (wave & 3) * 128;
-    const int n_units = sc.n_real * sc.ntn;
-    const int ntiles = (n_units - sc.b + sc.G - 1) / sc.G;   // 0 when every real tile went to lower-numbered workgroups
+    const int ntiles = p_ntiles(sc);                         // 0 when every real tile went to other workgroups
     // M-tile ids of this workgroup's tiles (<= 64 per workgroup: guaranteed by the launcher when a tile map is used);
     // loaded separately in the two roles so that the consumers' register pressure cannot spill the loaders' copy
     auto load_mt_list = [&]() -> unsigned {
         unsigned v = 0;
         if (sc.tmap) {
-            const int u = sc.b + lane * sc.G;
-            if (u < n_units) v = (unsigned)sc.tmap[1 + u % sc.n_real];          // (n_units > 0 implies n_real > 0)
+            int mi, nt;
+            if (p_unit(sc, lane, mi, nt)) v = (unsigned)sc.tmap[1 + mi];
         }
         return v;
     };
@@ -538,6 +563,9 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     sc.n_real = ntm; sc.n_pad = 0;
     sc.G = (int)((long)ntm * ntn < cus ? (long)ntm * ntn : cus);
     const int taps = a.taps;
+    static const int order_env = fs2_dev_env("FS2_P_ORDER", -1);
+    sc.order = (taps == 1 && ntn >= 2 && sc.G % 8 == 0 && (long)a.N * a.Cin * 2 <= (3 << 19)) ? 1 : 0;     // weights <= 1.5 MB
+    if (order_env >= 0) sc.order = (order_env == 1 && sc.G % 8 == 0) ? 1 : 0;
     (void)abl;
 #ifdef FS2_DEV
     switch (abl) {

@@ -306,6 +306,8 @@ struct BnArgs {
     const void* x; const void* dout; const void* res; void* out;
     const float* mean_rstd; const float* gamma; const float* beta;
     float* sums;                 // stats / bwd sums (2C floats, atomically accumulated)
+    float* acc_dbeta; float* acc_dgamma;   // MODE 3 (optional): parameter gradients += sums (workgroup 0)
+    float* clear;                // MODE 3 (optional): 2C floats zeroed by workgroup 0 (the NEXT call's sums)
     int M, C, cprp, rows_per_block, act;
     float p; uint64_t seed; const uint64_t* seed_dev;
 };
@@ -346,6 +348,15 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
                 mu[k] = a.mean_rstd[c + k]; rs[k] = a.mean_rstd[a.C + c + k]; gm[k] = a.gamma[c + k]; bt[k] = a.beta[c + k];
                 if (MODE == 3) { m1[k] = a.sums[c + k] / (float)a.M; m2[k] = a.sums[a.C + c + k] / (float)a.M; }
             }
+        }
+    }
+    if (MODE == 3 && blockIdx.x == 0 && rl == 0 && cok) {
+        // the reduced sums ARE the affine gradients (sum g = dbeta, sum g*xhat = dgamma): workgroup 0 adds them into the
+        // parameter-gradient buffers and clears the workspace the next call reduces into (ping-pong: nobody reads that one now)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (a.acc_dbeta) { a.acc_dbeta[c + k] += a.sums[c + k]; a.acc_dgamma[c + k] += a.sums[a.C + c + k]; }
+            if (a.clear) { a.clear[c + k] = 0.f; a.clear[a.C + c + k] = 0.f; }
         }
     }
     float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
@@ -478,6 +489,42 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
     }
     (void)gamma; (void)beta;
 }
+// Train-mode statistics in two launches and no housekeeping: shifted sums (MODE 0) -> ONE kernel that converts them, updates
+// the running statistics, writes mean / rstd, counts the batch (nn.BatchNorm1d.num_batches_tracked) and CLEARS the workspace
+// for the next call (the caller zeroes it once, when it allocates it).
+template <typename T>
+__global__ void bn_fix_finalize_kernel(const T* __restrict__ x, float* __restrict__ stats, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_rstd,
+                                       int M, int C, float eps, float momentum) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const float sh = Elem<T>::ld(x + c), s1 = stats[c], s2 = stats[C + c];
+    stats[c] = 0.f; stats[C + c] = 0.f;
+    const float sum = s1 + (float)M * sh, ssd = fmaxf(s2 - s1 * s1 / (float)M, 0.f);
+    const float mean = sum / (float)M, var = ssd / (float)M;
+    mean_rstd[c] = mean;
+    mean_rstd[C + c] = rsqrtf(var + eps);
+    if (running_mean) {
+        const float unb = M > 1 ? ssd / (float)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                  float* mean_rstd, int M, int C, float eps, float momentum, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && stats_ws && mean_rstd, "bn_train_stats: null pointer");
+    FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_train_stats: bad shape M=%d C=%d", M, C);
+    BnArgs a = {};
+    a.x = x; a.sums = stats_ws;
+    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS);
+    BN_LAUNCH(0, 1024, grid);
+    if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
+    else bn_fix_finalize_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
+    FS2_CHECK_LAUNCH("bn_train_stats");
+    return FS2_OK;
+}
+
 extern "C" int fs2_bn_finalize(const float* stats, float* running_mean, float* running_var, float* mean_rstd, int M, int C,
                                float eps, float momentum, hipStream_t stream) {
     FS2_CHECK_ARG(stats && mean_rstd, "bn_finalize: null pointer");
@@ -519,5 +566,25 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     grid = bn_geometry(a, M, C, 256, 2048);
     BN_LAUNCH(3, 256, grid);
     FS2_CHECK_LAUNCH("bn_bwd");
+    return FS2_OK;
+}
+
+// the same in two launches and no housekeeping: `sums` must be zero on entry (2C floats), `sums_next` (the workspace the NEXT
+// call will pass as `sums`) is cleared by this call, and dgamma_acc / dbeta_acc (parameter-gradient buffers) += the sums.
+extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
+                              float* sums, float* sums_next, void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act,
+                              float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && dout && mean_rstd && gamma && beta && sums && sums_next && dx && dgamma_acc && dbeta_acc, "bn_bwd_acc: null pointer");
+    FS2_CHECK_ARG(C % 4 == 0 && C <= 1024 && sums != sums_next, "bn_bwd_acc: C=%d must be a multiple of 4, <= 1024; two distinct workspaces", C);
+    if (M == 0) return FS2_OK;
+    BnArgs a = {};
+    a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
+    a.p = p; a.seed = seed; a.seed_dev = seed_dev;
+    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS);
+    BN_LAUNCH(2, 1024, grid);
+    a.acc_dbeta = dbeta_acc; a.acc_dgamma = dgamma_acc; a.clear = sums_next;
+    grid = bn_geometry(a, M, C, 256, 2048);
+    BN_LAUNCH(3, 256, grid);
+    FS2_CHECK_LAUNCH("bn_bwd_acc");
     return FS2_OK;
 }

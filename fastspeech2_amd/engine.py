@@ -67,6 +67,7 @@ class Engine:
         self._side_keep = []
         self._pack_pending = False
         self._tmaps = {}
+        self._bn_ws = {}
 
     # ------------------------------------------------------------------ dropout stream
     _SEED_INC = 0x632BE59BD9B4E019 & 0x7FFFFFFFFFFFFFFF
@@ -226,6 +227,15 @@ class Engine:
             self.grad_hook(end, (self._side,) if self._side is not None else ())
 
     # ------------------------------------------------------------------ building blocks
+    def _bn_workspace(self, C):
+        """[forward statistics, backward sums A, backward sums B, parity] for C channels: zeroed ONCE here, kept zero by the
+        kernels themselves (fs2_bn_train_stats / fs2_bn_bwd_acc), shared by every BatchNorm layer of that width (stream order)."""
+        ws = self._bn_ws.get(C)
+        if ws is None:
+            z = torch.zeros(3, 2 * C, device=self.device, dtype=torch.float32)
+            ws = self._bn_ws[C] = [z[0], z[1], z[2], 0]
+        return ws
+
     def _tmap(self, lens):
         """tile map of a lengths tensor this forward registered (None otherwise: the non-persistent kernels run)."""
         return self._tmaps.get(lens.data_ptr()) if lens is not None else None
@@ -496,8 +506,8 @@ class Engine:
             if training:
                 h_out, mean_rstd = ops.bn_train_fwd(c, P[pre + "1.weight"], P[pre + "1.bias"], self.Bf[pre + "1.running_mean"],
                                                     self.Bf[pre + "1.running_var"], act, p_pn, _seed_pair(200 + i, seed_dev)[0], res=res,
-                                                    seed_dev=_seed_pair(200 + i, seed_dev)[1])
-                self.Bf[pre + "1.num_batches_tracked"] += 1
+                                                    seed_dev=_seed_pair(200 + i, seed_dev)[1], ws=self._bn_workspace(c.shape[1])[0],
+                                                    num_batches_tracked=self.Bf[pre + "1.num_batches_tracked"])
             else:
                 mean_rstd = torch.cat([self.Bf[pre + "1.running_mean"], torch.rsqrt(self.Bf[pre + "1.running_var"] + 1e-5)])
                 h_out = torch.empty_like(c)
@@ -558,10 +568,12 @@ class Engine:
         for i in reversed(range(5)):
             pre = f"postnet.convolutions.{i}."
             s = sv.pn[i]
-            dc, dgam, dbet = ops.bn_bwd(s.c, g, s.mean_rstd, P[pre + "1.weight"], P[pre + "1.bias"], s.act, sv.p_pn,
-                                        _seed_pair(200 + i, seed_dev)[0], seed_dev=_seed_pair(200 + i, seed_dev)[1])
-            G[pre + "1.weight"] += dgam
-            G[pre + "1.bias"] += dbet
+            ws = self._bn_workspace(s.c.shape[1])
+            k = ws[3]
+            ws[3] = 1 - k                               # ping-pong: this call reduces into ws[1+k] and clears ws[2-k] for the next one
+            dc = ops.bn_bwd_acc(s.c, g, s.mean_rstd, P[pre + "1.weight"], P[pre + "1.bias"], s.act, sv.p_pn,
+                                _seed_pair(200 + i, seed_dev)[0], ws[1 + k], ws[2 - k], G[pre + "1.weight"], G[pre + "1.bias"],
+                                seed_dev=_seed_pair(200 + i, seed_dev)[1])
             self._wgrad(G[pre + "0.conv.weight"], G[pre + "0.conv.bias"], dc, s.x, T, taps=5, pad=2)
             g = self._dgemm(W, pre + "0.conv", dc, T, taps=5, pad=2, res=dpost if i == 0 else None)
         dmel_total = ops.add(g, dmel)

@@ -54,10 +54,10 @@ def run():
     print("RESULT " + ";".join(f"{n}|{us:.1f}|{tf:.0f}" for n, us, tf in out), flush=True)
 
 
-def sweep():
-    cfgs = [("ring/128 (P off)", {"FS2_GEMM_P": "0"}), ("persistent", {}), ("P no-MFMA", {"FS2_GEMM_ABL": "1"}),
+def sweep(custom=None):
+    cfgs = [(c, dict(kv.split("=") for kv in c.split(",") if kv)) for c in custom] if custom else [("ring/128 (P off)", {"FS2_GEMM_P": "0"}), ("persistent", {}), ("P no-MFMA", {"FS2_GEMM_ABL": "1"}),
             ("P no-reads", {"FS2_GEMM_ABL": "2"}), ("P no-MFMA no-reads", {"FS2_GEMM_ABL": "3"}), ("P no-epilogue", {"FS2_GEMM_ABL": "4"}),
-            ("P no-DMA", {"FS2_GEMM_ABL": "8"}), ("P no-DMA no-reads", {"FS2_GEMM_ABL": "10"}), ("P no-DMA no-epilogue", {"FS2_GEMM_ABL": "12"})]
+            ]
     rows = {}
     for tag, env in cfgs:
         e = dict(os.environ)
@@ -77,4 +77,9 @@ def sweep():
 
 
 if __name__ == "__main__":
-    sweep() if len(sys.argv) > 1 and sys.argv[1] == "sweep" else run()
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        sweep()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ab":          # python tools/bench_p.py ab FS2_P_ORDER=0 FS2_P_ORDER=1,FS2_X=2 ...
+        sweep(sys.argv[2:])
+    else:
+        run()

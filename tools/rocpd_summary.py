@@ -71,3 +71,28 @@ if len(sys.argv) > 3:
         ksum = c.execute("select sum(end-start) from kernels where start >= ? and end <= ?", (w0, w1)).fetchone()[0]
         print(f"\n## steady state ({nst} steps)\n\n{(w1-w0)/1e6/nst:.3f} ms/step wall; device busy {busy/1e6/nst:.3f} ms/step, idle {gsum/1e6/nst:.3f} ms/step in {ngap/nst:.0f} gaps; "
               f"sum of kernel durations {ksum/1e6/nst:.3f} ms/step (overlap factor {ksum/busy:.2f})")
+
+# ---- where the idle time sits (steady state): the largest gaps with the kernels on either side, and gap time summed by the
+# kernel that FOLLOWS the gap (= what the host was late to launch)
+if len(sys.argv) > 3:
+    ad = c.execute(f"select end from kernels where {name_col} like '%adam_kernel%' order by end").fetchall()
+    if len(ad) >= 5:
+        w0, w1 = ad[2][0], ad[-1][0]
+        nst = len(ad) - 3
+        iv = c.execute(f"select start, end, {name_col} from kernels where end > ? and start < ? order by start", (w0, w1)).fetchall()
+        gaps, cur_e, cur_n = [], iv[0][1], iv[0][2]
+        for s0, e0, n in iv[1:]:
+            if s0 > cur_e:
+                gaps.append((s0 - cur_e, cur_n, n))
+            if e0 > cur_e:
+                cur_e, cur_n = e0, n
+        short = lambda n: re.sub(r"\(.*", "", n).replace("void ", "")[:46]
+        by_next = {}
+        for g, p, n in gaps:
+            d = by_next.setdefault(short(n), [0, 0]); d[0] += g; d[1] += 1
+        print("\n## idle time by the kernel that follows the gap (steady state)\n\n| next kernel | gaps/step | idle us/step | avg gap us |\n|---|---|---|---|")
+        for k, (g, cnt) in sorted(by_next.items(), key=lambda kv: -kv[1][0])[:18]:
+            print(f"| {k} | {cnt/nst:.1f} | {g/1e3/nst:.1f} | {g/cnt/1e3:.1f} |")
+        print("\n## largest gaps\n\n| gap us | after | before |\n|---|---|---|")
+        for g, p, n in sorted(gaps, reverse=True)[:14]:
+            print(f"| {g/1e3:.1f} | {short(p)} | {short(n)} |")
