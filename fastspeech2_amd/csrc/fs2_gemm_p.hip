@@ -57,11 +57,10 @@ struct PSched {
     int ntm, ntn;              // M-tiles (real + padded), N-tiles
     int n_real, n_pad;         // real / padded M-tiles (read from the tile map on the device)
     const int32_t* tmap;       // [0] = n_real, [1 .. ntm] = real M-tiles then padded M-tiles; null = identity (no lens)
-    int order;                 // 0: M-fastest over all workgroups (neighbours share the weight slice - convolutions, whose
-                               //    weights exceed an XCD's L2 when every N-tile is live at once);
+    int order;                 // 0: M-fastest over all workgroups (neighbours share the weight slice);
                                // 1: per XCD, N-fastest: the G/8 workgroups the dispatcher places on one XCD (b % 8) walk ALL
                                //    N-tiles of the same M-tile together, so the activation tile is fetched into that XCD's L2
-                               //    once instead of once per N-tile (taps == 1 with small weights: QKV re-read its input 6x)
+                               //    once instead of once per N-tile (QKV re-read its input 6x from the Infinity Cache)
 };
 
 // index (into the real-M-tile list) and N-tile of the k-th tile of workgroup s.b; false when the workgroup has no k-th tile
@@ -564,7 +563,10 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     sc.G = (int)((long)ntm * ntn < cus ? (long)ntm * ntn : cus);
     const int taps = a.taps;
     static const int order_env = fs2_dev_env("FS2_P_ORDER", -1);
-    sc.order = (taps == 1 && ntn >= 2 && sc.G % 8 == 0 && (long)a.N * a.Cin * 2 <= (3 << 19)) ? 1 : 0;     // weights <= 1.5 MB
+    // r02e same-box A/B: per-XCD N-fastest is faster wherever an M-tile has >= 2 N-tiles and the launch has at least two
+    // rounds of tiles (QKV 51.9 -> 43.8 us, k=1 FFN data gradient 60.1 -> 51.9, k=9 data gradient 218 -> 209, PostNet k=5
+    // 113.5 -> 107.6; the N = 1024 forward conv is unchanged, the 192-tile encoder conv 4 % slower)
+    sc.order = (ntn >= 2 && sc.G % 8 == 0 && (long)ntm * ntn >= 2L * cus) ? 1 : 0;
     if (order_env >= 0) sc.order = (order_env == 1 && sc.G % 8 == 0) ? 1 : 0;
     (void)abl;
 #ifdef FS2_DEV
