@@ -933,8 +933,8 @@ static void launch_skinny(const ConvGemmArgs& a, hipStream_t stream) {
 }
 
 // defined in fs2_gemm_p.hip
-bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype);
-void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl);
+bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks);
+void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl, int ks, float* ws);
 
 // Which kernel a launch description dispatches to: a PURE function of the description (no state, no environment in the
 // shipped build), shared by fs2_conv_gemm and by the query entry point fs2_conv_gemm_variant that bench.py uses to attribute
@@ -965,7 +965,7 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map) {
     // persistent 256x128 kernel (fs2_gemm_p.hip): every shape the ring kernel takes plus the short-K one-tap contractions
     // (its run-ahead loaders hide the per-tile ring fill those could not amortise).  FS2_GEMM_P=0: dev A/B against the ring.
     static const int p_on = fs2_dev_env("FS2_GEMM_P", 1);
-    const bool persist = p_on && !skinny && fs2_conv_gemm_p_ok(a, has_map, dtype) && (taps > 1 || Cin >= 256);
+    const bool persist = p_on && !skinny && fs2_conv_gemm_p_ok(a, has_map, dtype, 1) && (taps > 1 || Cin >= 256);
     // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
     static const int ksplit_on = fs2_dev_env("FS2_GEMM_KSPLIT", 1);
     p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= 32;
@@ -1019,7 +1019,7 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
         else launch_skinny<128>(a, stream);
     } else if (pk.variant == FS2_GEMM_PERSIST || pk.variant == FS2_GEMM_PERSIST_1TAP) {
         static const int abl = fs2_dev_env("FS2_GEMM_ABL", 0);
-        fs2_conv_gemm_p_launch(a, tile_map, stream, abl);
+        fs2_conv_gemm_p_launch(a, tile_map, stream, abl, 1, nullptr);
     } else if (pk.variant == FS2_GEMM_RING) {
         static Fs2DevOnce ring_once;
         const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
@@ -1049,6 +1049,26 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     } else if (dtype == FS2_F32) conv_gemm_kernel<float><<<(unsigned)grid, 256, 0, stream>>>(a);
     else conv_gemm_kernel<bf16_t><<<(unsigned)grid, 256, 0, stream>>>(a);
     FS2_CHECK_LAUNCH("conv_gemm");
+    return FS2_OK;
+}
+
+// K-split form of fs2_conv_gemm for contractions with few output tiles and a long reduction (the encoder's k=9 data gradient:
+// 48 tiles x 144 K-steps on 256 CUs): `ksplit` workgroups share one output tile, each reduces a contiguous range of Cin
+// chunks and adds its partial tile into `ws` (f32, M x N, ZERO on entry, zero again on exit); one more launch applies bias /
+// activation / residual and writes Y.  Only shapes the persistent kernel takes (bf16, Cin % (64 ksplit) == 0, N % 8 == 0,
+// 16-byte rows, lens only together with tile_map); FS2_EINVAL otherwise - the caller falls back to fs2_conv_gemm.
+extern "C" int fs2_conv_gemm_splitk(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
+                                    long ldy, const int32_t* lens, const int32_t* tile_map, float* ws, int ksplit, int M, int N,
+                                    int Cin, int S, int taps, int dil, int pad, int act, float slope, float out_scale, int dtype,
+                                    hipStream_t stream) {
+    FS2_CHECK_ARG(X && W && Y && ws, "conv_gemm_splitk: null pointer");
+    FS2_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && S > 0 && taps > 0 && dil > 0 && M % S == 0 && ksplit >= 2, "conv_gemm_splitk: bad shape");
+    FS2_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ldx % 8 == 0, "conv_gemm_splitk: alignment");
+    ConvGemmArgs a;
+    conv_gemm_fill(a, X, ldx, W, bias, R, ldr, Y, ldy, lens, M, N, Cin, S, taps, dil, pad, act, slope, FS2_ACT_NONE, 0.f, 0, out_scale, dtype);
+    FS2_CHECK_ARG(fs2_conv_gemm_p_ok(a, tile_map != nullptr, dtype, ksplit), "conv_gemm_splitk: shape not supported (M=%d N=%d Cin=%d taps=%d ksplit=%d)", M, N, Cin, taps, ksplit);
+    fs2_conv_gemm_p_launch(a, tile_map, stream, 0, ksplit, ws);
+    FS2_CHECK_LAUNCH("conv_gemm_splitk");
     return FS2_OK;
 }
 

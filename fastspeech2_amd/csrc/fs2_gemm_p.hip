@@ -57,38 +57,48 @@ struct PSched {
     int ntm, ntn;              // M-tiles (real + padded), N-tiles
     int n_real, n_pad;         // real / padded M-tiles (read from the tile map on the device)
     const int32_t* tmap;       // [0] = n_real, [1 .. ntm] = real M-tiles then padded M-tiles; null = identity (no lens)
+    int ks, nkc_u;             // K-splits per output tile (1 = none) and Cin chunks per unit (= Cin/64/ks).  ks > 1: every unit
+                               // adds its partial 256x128 tile into the f32 workspace `ws` (M x N, zero before the launch) and
+                               // splitk_finalize_kernel turns it into the bf16 output - for few-tile, long-reduction shapes
+                               // (the encoder's k=9 data gradient: 48 tiles x 144 K-steps on 256 CUs)
+    float* ws;
     int order;                 // 0: M-fastest over all workgroups (neighbours share the weight slice);
                                // 1: per XCD, N-fastest: the G/8 workgroups the dispatcher places on one XCD (b % 8) walk ALL
                                //    N-tiles of the same M-tile together, so the activation tile is fetched into that XCD's L2
                                //    once instead of once per N-tile (QKV re-read its input 6x from the Infinity Cache)
 };
 
-// index (into the real-M-tile list) and N-tile of the k-th tile of workgroup s.b; false when the workgroup has no k-th tile
-__device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt) {
+// index (into the real-M-tile list), N-tile and K-split of the k-th unit of workgroup s.b; false when it has no k-th unit
+__device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt, int& sp) {
     if (s.order == 0) {
         const int u = s.b + k * s.G;
-        if (u >= s.n_real * s.ntn) return false;
-        nt = u / s.n_real;
-        mi = u - nt * s.n_real;
+        if (u >= s.n_real * s.ntn * s.ks) return false;
+        const int rest = u / s.ks;
+        sp = u - rest * s.ks;
+        nt = rest / s.n_real;
+        mi = rest - nt * s.n_real;
         return true;
     }
-    const int x = s.b & 7, j = s.b >> 3, pos = k * (s.G >> 3) + j;
-    const int mil = pos / s.ntn;
-    nt = pos - mil * s.ntn;
+    const int x = s.b & 7, j = s.b >> 3, pos = k * (s.G >> 3) + j, per = s.ntn * s.ks;
+    const int mil = pos / per, r = pos - mil * per;
+    nt = r / s.ks;
+    sp = r - nt * s.ks;
     mi = x + 8 * mil;
     return mi < s.n_real;
 }
 __device__ __forceinline__ int p_ntiles(const PSched& s) {
-    if (s.order == 0) return (s.n_real * s.ntn - s.b + s.G - 1) / s.G;
+    if (s.order == 0) return (s.n_real * s.ntn * s.ks - s.b + s.G - 1) / s.G;
     const int x = s.b & 7, j = s.b >> 3, g8 = s.G >> 3;
     const int nx = s.n_real > x ? (s.n_real - x + 7) >> 3 : 0;
-    return (nx * s.ntn - j + g8 - 1) / g8;
+    return (nx * s.ntn * s.ks - j + g8 - 1) / g8;
 }
 
-// k-th tile of this workgroup -> (M-tile, N-tile); the M-tile ids of a workgroup's first 64 tiles sit in `mt_list` (lane k)
-__device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_list, int& mt, int& nt) {
-    int mi;
-    (void)p_unit(s, k, mi, nt);
+// k-th unit of this workgroup -> (M-tile, N-tile, first Cin chunk); the M-tile ids of a workgroup's first 64 units sit in
+// `mt_list` (lane k)
+__device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_list, int& mt, int& nt, int& kc0) {
+    int mi, sp;
+    (void)p_unit(s, k, mi, nt, sp);
+    kc0 = __builtin_amdgcn_readfirstlane(sp * s.nkc_u);      // wave-uniform by construction; tell the compiler (SGPR operand of the DMA)
     mt = s.tmap ? (int)__builtin_amdgcn_readlane(mt_list, k) : mi;
 }
 
@@ -100,11 +110,12 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     constexpr int D = C::D, NJA = C::NJA;
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(a.X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(a.W);
-    const int nkc = a.Cin >> 6;
+    const int nkc = sc.nkc_u;                                // Cin chunks per unit (a K-split owns a contiguous range of chunks)
     const int taps = ONE_TAP ? 1 : a.taps;
     const int nsteps = taps * nkc;
-    const int total = ntiles * nsteps;                       // K-steps of this workgroup, all tiles
+    const int total = ntiles * nsteps;                       // K-steps of this workgroup, all units
     const int nchunks = ntiles * nkc;
+    int kc0A = 0, kc0B = 0;                                  // first chunk of the unit the A / B offsets are set for
     const int lr = lane >> 3, lc = lane & 7;
     const int arows = 256 + (taps - 1) * a.dil;
     const unsigned smem_base = lds_addr(smem);
@@ -112,7 +123,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     unsigned offA[NJA], ldsA[NJA], offB[4];
     auto set_A = [&](int k) {
         int mt, nt;
-        p_tile_of(sc, k, mt_list, mt, nt);
+        p_tile_of(sc, k, mt_list, mt, nt, kc0A);
         const int m0 = mt * 256;
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
@@ -126,7 +137,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     };
     auto set_B = [&](int k) {
         int mt, nt;
-        p_tile_of(sc, k, mt_list, mt, nt);
+        p_tile_of(sc, k, mt_list, mt, nt, kc0B);
         const int n0 = nt * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -140,7 +151,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     int kA = -1, kB = -1;                                    // tiles the per-lane offsets are set for
     auto issue_A = [&](int k, int kc, int buf_or_slot) {
         if (k != kA) { set_A(k); kA = k; }
-        const unsigned char* base = Xb + (size_t)kc * 128;
+        const unsigned char* base = Xb + (size_t)(kc0A + kc) * 128;
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
             const unsigned d = (ldsA[j] == 0xffffffffu) ? smem_base + C::SCRATCH : smem_base + buf_or_slot * C::A_BYTES + ldsA[j];
@@ -150,7 +161,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     auto issue_step = [&]() {                                // operands of global step `is` -> slot `islot`
         if (ik != kB) { set_B(ik); kB = ik; }
         if (ONE_TAP) issue_A(ik, ikc, islot);
-        const unsigned char* base = Wb + ((size_t)itap * a.Cin + (size_t)ikc * 64) * 2;
+        const unsigned char* base = Wb + ((size_t)itap * a.Cin + (size_t)(kc0B + ikc) * 64) * 2;
         const unsigned d0 = smem_base + C::B_OFF + islot * P_B_BYTES + lw * 4096;
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16_sbase(offB[j], base, d0 + j * 1024);
@@ -276,13 +287,83 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
     }
 }
 
+// K-split epilogue: the partial tile is ADDED into the f32 workspace (hardware float atomics; same lane layout as above: after
+// the half-wave swap a lane holds 2 x 8 consecutive columns of one row).  Bias / activation / residual happen once, in
+// splitk_finalize_kernel.
+__device__ __forceinline__ void p_epilogue_splitk(const ConvGemmArgs& a, float* ws, f32x16 (&acc)[2][4], int m0, int n0, int wm,
+                                                  int fl, int fh) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + wm * 64 + mb * 32 + fl;
+        if (m >= a.M) continue;
+        float* wrow = ws + (size_t)m * a.N;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            float c[2][8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][e]), __float_as_uint(acc[mb][nb][4 + e]), false, false);
+                u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][8 + e]), __float_as_uint(acc[mb][nb][12 + e]), false, false);
+                c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
+                c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int n = n0 + nb * 32 + ch * 16 + fh * 8;
+                if (n >= a.N) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) unsafeAtomicAdd(wrow + n + e, c[ch][e]);
+            }
+        }
+    }
+}
+
+// ws (f32, M x N) -> Y: bias, activation, residual / gate, scale, padded-row zero, bf16; ws is CLEARED on the way (the caller
+// zeroes it once when it allocates it; every launch leaves it zero again).  One thread = 8 consecutive columns of one row.
+template <int ACT>
+__global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, float* __restrict__ ws) {
+    const int cpr = a.N >> 3;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.M * cpr) return;
+    const int m = (int)(idx / cpr), n = (int)(idx - (long)m * cpr) * 8;
+    float* wp = ws + (size_t)m * a.N + n;
+    const float4 x0 = *reinterpret_cast<const float4*>(wp), x1 = *reinterpret_cast<const float4*>(wp + 4);
+    *reinterpret_cast<float4*>(wp) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(wp + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a.bias[n + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(v[e], a.slope);
+    const bool gate = a.act == FS2_ACT_GATE;
+    if (a.R) {
+        const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.R) + (size_t)m * a.ldr + n);
+        const uint32_t* u = reinterpret_cast<const uint32_t*>(&rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+            v[2 * e] = gate ? (r0 > 0.f ? v[2 * e] : 0.f) : v[2 * e] + r0;
+            v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
+        }
+    }
+    bool padrow = false;
+    if (a.lens) { const int b = m / a.S; padrow = (m - b * a.S) >= a.lens[b]; }
+    uint4 o;
+    uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ou[e] = padrow ? 0u : pack_bf16x2(v[2 * e] * a.out_scale, v[2 * e + 1] * a.out_scale);
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = o;
+}
+
 // ABL (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue
 template <bool ONE_TAP, int ABL>
 __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int wm,
                                            unsigned mt_list, int ntiles, const int32_t* lens_s, float* bias_s) {
     typedef PCfg<ONE_TAP> C;
     constexpr int D = C::D;
-    const int nkc = a.Cin >> 6;
+    const int nkc = sc.nkc_u;
     const int taps = ONE_TAP ? 1 : a.taps;
     const int nsteps = taps * nkc;
     const int total = ntiles * nsteps;
@@ -350,8 +431,8 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
     }
     for (int k = 0; k < ntiles; ++k) {
-        int mt, nt;
-        p_tile_of(sc, k, mt_list, mt, nt);
+        int mt, nt, kc0_unused;
+        p_tile_of(sc, k, mt_list, mt, nt, kc0_unused);
         const int m0 = mt * 256, n0 = nt * 128;
         // tap-validity bits of this lane's two rows (bit j: tap j stays inside the row's own sequence)
         unsigned vmask[2] = {0xffffffffu, 0xffffffffu};
@@ -408,9 +489,16 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
             }
         };
         if (need_mask) run_tile(std::true_type{}); else run_tile(std::false_type{});
-        if (k + 1 == ntiles) FS2P_WAIT_LGKM(0);               // the dangling prefetch of the last step
+        // The six fragments prefetched for the NEXT unit's first k-slice are in flight here and stay in registers across the
+        // epilogue.  The masked and unmasked loops are separate code with their own register assignment, so the compiler may
+        // COPY those registers at a unit boundary - and a copy of a register whose read is still in flight carries stale data
+        // (seen in the round-2 "v3" experiment: whole 32-row blocks of the last-issued fragment wrong in a few tiles).  Land
+        // them first, AS OUTPUTS of the wait, so every copy is ordered behind it (one LDS drain per tile, not per step).
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
 
-        if (!(ABL & 4)) {
+        if (sc.ks > 1) {
+            p_epilogue_splitk(a, sc.ws, acc, m0, n0, wm, fl, fh);
+        } else if (!(ABL & 4)) {
             FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wm, fl, fh, lens_s, bias_s, lane)));
         } else {
             float s = 0.f;
@@ -446,8 +534,8 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
     auto load_mt_list = [&]() -> unsigned {
         unsigned v = 0;
         if (sc.tmap) {
-            int mi, nt;
-            if (p_unit(sc, lane, mi, nt)) v = (unsigned)sc.tmap[1 + mi];
+            int mi, nt, sp;
+            if (p_unit(sc, lane, mi, nt, sp)) v = (unsigned)sc.tmap[1 + mi];
         }
         return v;
     };
@@ -458,7 +546,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
             for (int i = tid; i < B; i += 256) lens_s[i] = a.lens[i];
         }
         // fully padded tiles of this workgroup: zeros (while the loaders fill the rings)
-        if (!a.accumulate && sc.n_pad > 0) {
+        if (!a.accumulate && sc.n_pad > 0 && sc.ks == 1) {      // (K-split launches: splitk_finalize_kernel writes every row)
             bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
             const int n_pu = sc.n_pad * sc.ntn;
             for (int p = sc.b; p < n_pu; p += sc.G) {
@@ -536,16 +624,17 @@ static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream
 }
 
 // Eligibility of the persistent kernel (pure function of the launch description; shared with fs2_conv_gemm_variant).
-bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype) {
+bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks) {
     if (dtype != FS2_BF16 || a.in_act != FS2_ACT_NONE) return false;
     const int taps = a.taps;
     if (!(taps == 1 || (taps >= 3 && (taps - 1) * a.dil <= 16 && taps <= 32))) return false;
     if (a.Cin % 64 != 0 || !a.vec_ok || a.N % 8 != 0) return false;
     if ((double)a.M * a.ldx * 2 >= 2.0e9 || (double)a.N * taps * a.Cin * 2 >= 2.0e9) return false;
-    const long tiles = (long)fs2_cdiv(a.M, 256) * fs2_cdiv(a.N, 128);
+    const long tiles = (long)fs2_cdiv(a.M, 256) * fs2_cdiv(a.N, 128) * ks;
+    if (ks > 1 && ((a.Cin >> 6) % ks != 0 || a.accumulate)) return false;
     if (a.lens && (!has_map || a.M / a.S > P_MAXB)) return false;
     const int cus = fs2_cu_count();
-    if (tiles < cus / 2) return false;                       // too few tiles to fill the chip: the 128^2 kernels do better
+    if (tiles < (ks > 1 ? cus / 4 : cus / 2)) return false;  // too few tiles to fill the chip: the 128^2 kernels do better
     const long G = tiles < cus ? tiles : cus;
     if (a.lens && (tiles + G - 1) / G > 64) return false;    // a workgroup's M-tile ids travel in one VGPR (lane k = k-th tile)
     return true;
@@ -553,20 +642,21 @@ bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype) {
 
 // The real-tile count lives in tile_map[0] on the device; the launch geometry must not depend on it (no host sync), so
 // G = min(CUs, all tiles) and workgroups that find no real tile only zero-fill their share of the padded ones.
-void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl) {
+void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl, int ks, float* ws) {
     const int ntm = fs2_cdiv(a.M, 256), ntn = fs2_cdiv(a.N, 128);
     const int cus = fs2_cu_count();
     PSched sc;
+    sc.ks = ks; sc.nkc_u = (a.Cin >> 6) / ks; sc.ws = ws;
     sc.tmap = a.lens ? tile_map : nullptr;
     sc.ntm = ntm; sc.ntn = ntn; sc.b = 0;
     sc.n_real = ntm; sc.n_pad = 0;
-    sc.G = (int)((long)ntm * ntn < cus ? (long)ntm * ntn : cus);
+    sc.G = (int)((long)ntm * ntn * ks < cus ? (long)ntm * ntn * ks : cus);
     const int taps = a.taps;
     static const int order_env = fs2_dev_env("FS2_P_ORDER", -1);
     // r02e same-box A/B: per-XCD N-fastest is faster wherever an M-tile has >= 2 N-tiles and the launch has at least two
     // rounds of tiles (QKV 51.9 -> 43.8 us, k=1 FFN data gradient 60.1 -> 51.9, k=9 data gradient 218 -> 209, PostNet k=5
     // 113.5 -> 107.6; the N = 1024 forward conv is unchanged, the 192-tile encoder conv 4 % slower)
-    sc.order = (ntn >= 2 && sc.G % 8 == 0 && (long)ntm * ntn >= 2L * cus) ? 1 : 0;
+    sc.order = (ntn >= 2 && sc.G % 8 == 0 && (long)ntm * ntn * ks >= 2L * cus) ? 1 : 0;
     if (order_env >= 0) sc.order = (order_env == 1 && sc.G % 8 == 0) ? 1 : 0;
     (void)abl;
 #ifdef FS2_DEV
@@ -579,4 +669,8 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     }
 #endif
     if (taps == 1) launch_p<true, 0>(a, sc, stream); else launch_p<false, 0>(a, sc, stream);
+    if (ks > 1) {
+        const long chunks = (long)a.M * (a.N >> 3);
+        FS2_ACT_DISPATCH(a.act, (splitk_finalize_kernel<ACT><<<(unsigned)((chunks + 255) / 256), 256, 0, stream>>>(a, ws)));
+    }
 }

@@ -68,6 +68,7 @@ class Engine:
         self._pack_pending = False
         self._tmaps = {}
         self._bn_ws = {}
+        self._splitk_ws = {}
 
     # ------------------------------------------------------------------ dropout stream
     _SEED_INC = 0x632BE59BD9B4E019 & 0x7FFFFFFFFFFFFFFF
@@ -247,7 +248,15 @@ class Engine:
     def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None, lens=None):
         """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
         _, wd, _, shape = W[key]
-        return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens, tmap=self._tmap(lens))
+        M, N, Cin = dy.shape[0], wd.shape[0], wd.shape[-1]
+        ks = ops.splitk_for(M, N, Cin, taps, dy.dtype) if (lens is None or self._tmap(lens) is not None) else 1
+        ws = None
+        if ks > 1:                                  # persistent zero workspace (the finalize launch clears it again)
+            ws = self._splitk_ws.get((M, N))
+            if ws is None:
+                ws = self._splitk_ws[(M, N)] = torch.zeros(M, N, device=dy.device, dtype=torch.float32)
+        return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens, tmap=self._tmap(lens),
+                             ksplit=ks, ws=ws)
 
     def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0, lens=None):
         """weight (+ bias) gradient of one contraction.  Weight gradients are OFF the critical path of backward (nothing

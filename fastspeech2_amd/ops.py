@@ -91,7 +91,7 @@ def pack_weight(w, dtype, want_fwd=True, want_dgrad=True, wf=None, wd=None):
 # ------------------------------------------------------------------ contraction
 def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0, lens=None, res=None, out=None,
               in_act=ACT_NONE, in_slope=0.0, accumulate=False, out_scale=1.0, ldx=None, M=None, Cin=None, N=None,
-              ldy=None, tmap=None):
+              ldy=None, tmap=None, ksplit=1, ws=None):
     """x: [M, Cin] rows (or any buffer with row stride ldx); wpacked: [N, taps, Cin]; returns [M, N].
     tmap: tile_map(lens, B, S) of the same lens (optional; lets the persistent kernel skip fully padded M-tiles)."""
     if M is None:
@@ -110,14 +110,33 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("fs2_conv_gemm", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), M, N, Cin, S,
-              taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
+    if ksplit > 1:      # few output tiles, long reduction: K-split workgroups + f32 workspace (zero between calls) + finalize launch
+        assert ws is not None and ws.numel() >= M * N and in_act == ACT_NONE and not accumulate
+        _lib.call("fs2_conv_gemm_splitk", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), _p(ws),
+                  ksplit, M, N, Cin, S, taps, dil, pad, act, slope, out_scale, dt(x), _stream())
+    else:
+        _lib.call("fs2_conv_gemm", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), M, N, Cin, S,
+                  taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
     if PROFILE is not None:
         e1.record()
-        var = _lib.load().fs2_conv_gemm_variant(ldx, ldy, ldr, int(lens is not None), int(tmap is not None), M, N, Cin, S, taps, dil,
-                                                in_act, in_slope, dt(x))
+        var = 5 if ksplit > 1 and taps > 1 else (6 if ksplit > 1 else
+              _lib.load().fs2_conv_gemm_variant(ldx, ldy, ldr, int(lens is not None), int(tmap is not None), M, N, Cin, S, taps, dil,
+                                                in_act, in_slope, dt(x)))
         PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, var, lens is not None, S))
     return out
+
+
+def splitk_for(M, N, Cin, taps, dtype):
+    """K-split depth for a contraction: > 1 only where the persistent kernel would have too few 256x128 output tiles to fill
+    the chip and the reduction is long (r02: encoder k=9 data gradient, 48 tiles x 144 K-steps: 115 us unsplit)."""
+    if dtype != torch.bfloat16 or Cin % 64 or N % 8:
+        return 1
+    tiles = ((M + 255) // 256) * ((N + 127) // 128)
+    steps = taps * (Cin // 64)
+    for ks in (4, 2):
+        if tiles * ks <= 256 and tiles < 128 and steps // ks >= 24 and (Cin // 64) % ks == 0 and tiles * ks >= 128:
+            return ks
+    return 1
 
 
 TILE_ROWS = 256      # M-tile height of the persistent contraction kernel (fs2_gemm_p.hip)

@@ -51,6 +51,13 @@ int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bia
  * fs2_tile_map: out[0] = number of REAL `rows`-row M-tiles of the [B*S] row space, out[1..] = their indices (ascending)
  * followed by the fully padded ones (all rows in one sequence's tail t >= lens[b]); out holds 1 + ceil(B*S/rows) ints. */
 int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, fs2_stream_t stream);
+/* K-split form for few-tile, long-reduction contractions: `ksplit` workgroups per output tile add partial tiles into ws
+ * (f32, M x N, zero on entry and zero again on exit), one more launch finalises (bias, activation, residual, bf16).
+ * bf16 only, Cin % (64 ksplit) == 0; FS2_EINVAL for unsupported shapes (fall back to fs2_conv_gemm). */
+int fs2_conv_gemm_splitk(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Y,
+                         long ldy, const int32_t* lens, const int32_t* tile_map, float* ws, int ksplit, int M, int N, int Cin,
+                         int S, int taps, int dil, int pad, int act, float slope, float out_scale, int dtype,
+                         fs2_stream_t stream);
 /* Which kernel fs2_conv_gemm dispatches a launch description to: a pure function (no state) - a measurement aid that
  * lets bench.py attribute HIP-event durations to the kernel names rocprofv3 reports.  has_lens / has_map: whether
  * lens / tile_map would be non-NULL; ldr = 0 without a residual operand. */

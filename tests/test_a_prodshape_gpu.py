@@ -113,6 +113,34 @@ def test_contraction_forward_and_dgrad_production_shapes(dev, dtype, name, Cin, 
     assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)) * valid, dtype, (name, "dgrad gate"))
 
 
+@pytest.mark.parametrize("ks", [2, 4])
+def test_splitk_contraction_matches_unsplit_reference(dev, ks):
+    """the encoder's k=9 data gradient shape (M = 48 x 128, N = 256, K = 9 x 1024) through the K-split path: partial tiles added
+    into the f32 workspace, finalize launch (residual, gate, padded rows); the workspace must come back zero."""
+    ops = _ops()
+    S, Cin, Cout, k = 128, 1024, 256, 9
+    M, pad = B * S, 4
+    g = torch.Generator().manual_seed(77 + ks)
+    lens = ragged_lens(S, seed=3).to(dev)
+    tmap = ops.tile_map(lens, B, S)
+    x = torch.randn(M, Cin, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(Cout, k, Cin, generator=g) / math.sqrt(Cin * k)).to(dev).to(torch.bfloat16)
+    res = torch.randn(M, Cout, generator=g).to(dev).to(torch.bfloat16)
+    ws = torch.zeros(M, Cout, device=dev)
+    ref = conv_ref_gpu(x, w, None, S, pad, lens=lens)
+    valid = (torch.arange(S, device=dev).unsqueeze(0) < lens.unsqueeze(1)).reshape(-1, 1)
+    assert ops.splitk_for(M, Cout, Cin, k, torch.bfloat16) == 4
+    for _ in range(2):                                                    # twice: the second call starts from the cleared workspace
+        y = ops.conv_gemm(x, w, None, S, taps=k, pad=pad, res=res, lens=lens, tmap=tmap, ksplit=ks, ws=ws)
+        assert_rounding_only(y, (ref + res.double()) * valid, torch.bfloat16, ("splitk res", ks))
+        assert not ws.any()
+    y = ops.conv_gemm(x, w, None, S, taps=k, pad=pad, act=ops.ACT_GATE, res=res, lens=lens, tmap=tmap, ksplit=ks, ws=ws)
+    assert_rounding_only(y, torch.where(res.double() > 0, ref, torch.zeros_like(ref)) * valid, torch.bfloat16, ("splitk gate", ks))
+    bias = torch.randn(Cout, generator=g).to(dev)
+    y = ops.conv_gemm(x, w, bias, S, taps=k, pad=pad, act=ops.ACT_RELU, ksplit=ks, ws=ws)            # no lens, bias + ReLU
+    assert_rounding_only(y, torch.relu(conv_ref_gpu(x, w, bias, S, pad)), torch.bfloat16, ("splitk relu", ks))
+
+
 @pytest.mark.parametrize("Cin,Cout,k", [(256, 1024, 9), (1024, 256, 1), (512, 512, 5), (256, 768, 1), (80, 512, 5)])
 def test_weight_gradient_production_shapes_bf16(dev, Cin, Cout, k):
     """conv_wgrad_bf16_kernel<3,0,8> / <3,2,8> / <1,0,4> at M = 44 400 with ragged lens: the split-K grids the bench runs."""
