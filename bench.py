@@ -71,7 +71,8 @@ def parse():
 def dev_environment():
     """Tamper evidence: the shipped library has no environment switches, but a development build (FS2_LIB_PATH -> -DFS2_DEV)
     does (ablations that SKIP work).  The bench refuses to run with any of them set and records which library it loaded."""
-    bad = sorted(k for k in os.environ if k.startswith("FS2_") and k not in ("FS2_BENCH_BACKEND", "FS2_BENCH_SHARE_GPU"))
+    # (FS2_LIB_PATH selects another BUILD of the library for same-box A/B runs; the line records which file was loaded)
+    bad = sorted(k for k in os.environ if k.startswith("FS2_") and k not in ("FS2_BENCH_BACKEND", "FS2_BENCH_SHARE_GPU", "FS2_LIB_PATH"))
     if bad:
         print(f"bench.py: refusing to run with development variables set: {bad}", file=sys.stderr)
         sys.exit(3)

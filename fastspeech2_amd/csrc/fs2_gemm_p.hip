@@ -634,7 +634,10 @@ bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks) 
     if (ks > 1 && ((a.Cin >> 6) % ks != 0 || a.accumulate)) return false;
     if (a.lens && (!has_map || a.M / a.S > P_MAXB)) return false;
     const int cus = fs2_cu_count();
-    if (tiles < (ks > 1 ? cus / 4 : cus / 2)) return false;  // too few tiles to fill the chip: the 128^2 kernels do better
+    // too few tiles to fill the chip: the 128^2 kernels do better - except long convolutions (r02f: the encoder's k=9 data
+    // gradient, 48 tiles x 144 K-steps: 100 us here, 115 us on the 128^2 kernel with in-workgroup split-K)
+    const bool long_conv = taps >= 3 && (long)taps * (a.Cin >> 6) >= 96 && tiles >= cus / 8;
+    if (tiles < (ks > 1 ? cus / 4 : cus / 2) && !long_conv) return false;
     const long G = tiles < cus ? tiles : cus;
     if (a.lens && (tiles + G - 1) / G > 64) return false;    // a workgroup's M-tile ids travel in one VGPR (lane k = k-th tile)
     return true;

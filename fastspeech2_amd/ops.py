@@ -127,15 +127,10 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
 
 
 def splitk_for(M, N, Cin, taps, dtype):
-    """K-split depth for a contraction: > 1 only where the persistent kernel would have too few 256x128 output tiles to fill
-    the chip and the reduction is long (r02: encoder k=9 data gradient, 48 tiles x 144 K-steps: 115 us unsplit)."""
-    if dtype != torch.bfloat16 or Cin % 64 or N % 8:
-        return 1
-    tiles = ((M + 255) // 256) * ((N + 127) // 128)
-    steps = taps * (Cin // 64)
-    for ks in (4, 2):
-        if tiles * ks <= 256 and tiles < 128 and steps // ks >= 24 and (Cin // 64) % ks == 0 and tiles * ks >= 128:
-            return ks
+    """K-split depth the engine uses for a contraction.  Always 1: measured (r02f, encoder k=9 data gradient, 48 output tiles x
+    144 K-steps) the f32-atomic partial tiles cost more than the idle CUs they fill - unsplit persistent kernel 100 us,
+    ksplit 2: 131 us, ksplit 4: 185 us (the 128^2 kernel with in-workgroup split: 115 us).  fs2_conv_gemm_splitk stays in the
+    ABI (tested) for shapes where that balance differs."""
     return 1
 
 
