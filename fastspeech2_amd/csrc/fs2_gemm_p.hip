@@ -594,6 +594,66 @@ __global__ void __launch_bounds__(64) tile_map_kernel(const int32_t* __restrict_
     }
 }
 
+// Everything the step derives from a lengths vector, in ONE launch (was ~7 tiny ones per vector: int32 cast, clamp, arange +
+// compare for the mask the model returns, two reductions for the loss's valid count, the tile map):
+//   lens32[b] = min(len[b], S)      mask[b][t] = t >= len[b] (bool, True = padding; reference utils/tools.py:91-99)
+//   count[0]  = sum_b lens32[b]      tile_map   = as fs2_tile_map (rows-row M-tiles; optional)
+__global__ void __launch_bounds__(256) lens_prep_kernel(const int64_t* __restrict__ lens, int B, int S, int rows,
+                                                        int32_t* __restrict__ lens32, unsigned char* __restrict__ mask,
+                                                        float* __restrict__ count, int32_t* __restrict__ tmap) {
+    if (blockIdx.x > 0) {                                    // mask: one byte per position
+        const long i0 = ((long)(blockIdx.x - 1) * 256 + threadIdx.x) * 4, n = (long)B * S;
+        for (int e = 0; e < 4; ++e) {
+            const long i = i0 + e;
+            if (i < n) { const int b = (int)(i / S); mask[i] = (i - (long)b * S) >= lens[b]; }
+        }
+        return;
+    }
+    __shared__ int s_sum[4];
+    int part = 0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const long l = lens[b];
+        const int v = (int)(l < 0 ? 0 : (l > S ? S : l));
+        lens32[b] = v;
+        part += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) count[0] = (float)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+    if (tmap && threadIdx.x < 64) {                          // the tile map reads the lengths straight from the int64 vector
+        const int lane = threadIdx.x, M = B * S, ntm = (M + rows - 1) / rows;
+        int n_real = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            int n = 0;
+            for (int base = 0; base < ntm; base += 64) {
+                const int tm = base + lane;
+                bool real = false, valid = tm < ntm;
+                if (valid) {
+                    const int m0 = tm * rows, mlast = min(m0 + rows - 1, M - 1);
+                    const int b0 = m0 / S, b1 = mlast / S;
+                    real = !(b0 == b1 && (long)(m0 - b0 * S) >= lens[b0]);
+                }
+                const bool pick = valid && (pass == 0 ? real : !real);
+                const unsigned long long msk = __builtin_amdgcn_ballot_w64(pick);
+                const int pos = n + __builtin_popcountll(msk & ((1ull << lane) - 1ull));
+                if (pick) tmap[1 + (pass == 0 ? 0 : n_real) + pos] = tm;
+                n += __builtin_popcountll(msk);
+            }
+            if (pass == 0) { n_real = n; if (lane == 0) tmap[0] = n; }
+        }
+    }
+}
+
+extern "C" int fs2_lens_prep(const int64_t* lens, int B, int S, int rows, int32_t* lens32, void* mask, float* count,
+                             int32_t* tile_map, hipStream_t stream) {
+    FS2_CHECK_ARG(lens && lens32 && mask && count && B > 0 && S > 0 && rows > 0, "lens_prep: bad arguments");
+    const long n = (long)B * S;
+    lens_prep_kernel<<<1 + (unsigned)((n + 1023) / 1024), 256, 0, stream>>>(lens, B, S, rows, lens32, (unsigned char*)mask, count, tile_map);
+    FS2_CHECK_LAUNCH("lens_prep");
+    return FS2_OK;
+}
+
 extern "C" int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, hipStream_t stream) {
     FS2_CHECK_ARG(lens && out && B > 0 && S > 0 && rows > 0, "tile_map: bad arguments");
     tile_map_kernel<<<1, 64, 0, stream>>>(lens, B * S, S, rows, out);

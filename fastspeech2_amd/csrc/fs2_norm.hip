@@ -6,7 +6,7 @@
 #include "fs2_common.h"
 
 #define FS2_LN_MAXV 8   // C <= 8*256 = 2048
-#define FS2_LN_BWD_GRID 512
+#define FS2_LN_BWD_GRID 1024
 
 struct LnArgs {
     void* y;               // in: GEMM output (bias included); overwritten with z = drop_pre(y) + res  (saved for bwd)

@@ -395,9 +395,10 @@ class Engine:
             (mel, post, p_pred, e_pred, logd), _ = self.forward(st)
         B = texts.shape[0]
         dev = texts.device
-        src_masks = torch.arange(max_src_len, device=dev).unsqueeze(0) >= src_lens.unsqueeze(1)
-        mel_masks = torch.arange(st.Tdec, device=dev).unsqueeze(0) >= st.mel_lens_out.unsqueeze(1)
-        return (mel, post, p_pred, e_pred, logd, st.d_rounded, src_masks, mel_masks, src_lens, st.mel_lens_out)
+        # the valid-position counts the loss normalises by came out of the same launches as the masks: hand them over on the
+        # tensor the loss receives (FastSpeech2Loss falls back to computing them when the attribute is absent)
+        st.mel_lens_out._fs2_counts = (st.counts, src_lens, max_src_len, st.Tdec)
+        return (mel, post, p_pred, e_pred, logd, st.d_rounded, st.src_masks, st.mel_masks, src_lens, st.mel_lens_out)
 
     def forward(self, st):
         with ops.pinned_stream():
@@ -423,8 +424,9 @@ class Engine:
         p_dec = self.tc["decoder_dropout"] if drop else 0.0
         p_vp = self.vp["dropout"] if drop else 0.0
         p_pn = 0.5 if drop else 0.0
-        src_lens32 = st.src_lens.to(torch.int32)
-        self._tmaps = {src_lens32.data_ptr(): ops.tile_map(src_lens32, B, L)}
+        st.counts = torch.empty(2, device=self.device, dtype=torch.float32)
+        src_lens32, st.src_masks, tmap_src = ops.lens_prep(st.src_lens, B, L, st.counts[0:1])
+        self._tmaps = {src_lens32.data_ptr(): tmap_src}
 
         # ---- encoder (transformer/Models.py:73-100)
         n_head = self.tc["encoder_head"]
@@ -473,8 +475,8 @@ class Engine:
         Tdec = T if ((not training) and T > self.max_seq_len) else min(T, self.max_seq_len)
         cum, idx, mel_len = ops.lr_index(dur, Tdec)
         st.mel_lens_out, st.Tdec = mel_len, Tdec
-        dec_lens32 = torch.clamp(mel_len, max=Tdec).to(torch.int32)
-        self._tmaps[dec_lens32.data_ptr()] = ops.tile_map(dec_lens32, B, Tdec)
+        dec_lens32, st.mel_masks, tmap_dec = ops.lens_prep(mel_len, B, Tdec, st.counts[1:2])
+        self._tmaps[dec_lens32.data_ptr()] = tmap_dec
         frame_level = (not pitch_phone) or (not energy_phone)
         pe_dec = self._pe(P["decoder.position_enc"], Tdec)
         sv.x_lr_in = None

@@ -384,7 +384,11 @@ class FastSpeech2Loss(nn.Module):
         # valid positions exactly as the masks the model returned (utils/tools.py:91-99): t < min(len, padded length)
         src_lens = src_lens.to(torch.int64)
         mel_lens = mel_lens.to(torch.int64)
-        counts = torch.stack([src_lens.clamp(max=L).sum(), mel_lens.clamp(max=T).sum()]).float()
+        pre = getattr(predictions[9], "_fs2_counts", None)       # computed next to the masks by the model's own forward
+        if pre is not None and pre[1] is predictions[8] and pre[2] == L and pre[3] == T:
+            counts = pre[0]
+        else:
+            counts = torch.stack([src_lens.clamp(max=L).sum(), mel_lens.clamp(max=T).sum()]).float()
         if self.count_reduce is not None:
             counts = self.count_reduce(counts)
         mel_t = mel_targets if mel_targets.dtype == torch.float32 else mel_targets.float()

@@ -137,6 +137,18 @@ def splitk_for(M, N, Cin, taps, dtype):
 TILE_ROWS = 256      # M-tile height of the persistent contraction kernel (fs2_gemm_p.hip)
 
 
+def lens_prep(lens, B, S, count_out):
+    """int64 lengths -> (lens32 clamped to S, bool padding mask (B, S), tile map); count_out (1-element float view) = sum of the
+    clamped lengths.  One launch (fs2_lens_prep)."""
+    dev = lens.device
+    lens = lens if (lens.dtype == torch.int64 and lens.is_contiguous()) else lens.to(torch.int64).contiguous()
+    lens32 = torch.empty(B, device=dev, dtype=torch.int32)
+    mask = torch.empty(B, S, device=dev, dtype=torch.bool)
+    tmap = torch.empty(1 + (B * S + TILE_ROWS - 1) // TILE_ROWS, device=dev, dtype=torch.int32)
+    _lib.call("fs2_lens_prep", _p(lens), B, S, TILE_ROWS, _p(lens32), _p(mask), _p(count_out), _p(tmap), _stream())
+    return lens32, mask, tmap
+
+
 def tile_map(lens, B, S):
     """[n_real, real 256-row M-tiles ..., fully padded M-tiles ...] of the [B*S] row space (device int32); see fs2_tile_map."""
     ntm = (B * S + TILE_ROWS - 1) // TILE_ROWS

@@ -51,6 +51,12 @@ int fs2_conv_gemm(const void* X, long ldx, const void* Wpacked, const float* bia
  * fs2_tile_map: out[0] = number of REAL `rows`-row M-tiles of the [B*S] row space, out[1..] = their indices (ascending)
  * followed by the fully padded ones (all rows in one sequence's tail t >= lens[b]); out holds 1 + ceil(B*S/rows) ints. */
 int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, fs2_stream_t stream);
+/* Everything a step derives from a lengths vector (int64, as the reference's batches carry them) in one launch:
+ * lens32[b] = min(len[b], S); mask[b][t] = (t >= len[b]) as bytes (the bool masks FastSpeech2.forward returns, True = padding,
+ * reference utils/tools.py:91-99); count[0] = sum_b lens32[b] (FastSpeech2Loss's valid-position count); tile_map as fs2_tile_map
+ * (optional). */
+int fs2_lens_prep(const int64_t* lens, int B, int S, int rows, int32_t* lens32, void* mask, float* count, int32_t* tile_map,
+                  fs2_stream_t stream);
 /* K-split form for few-tile, long-reduction contractions: `ksplit` workgroups per output tile add partial tiles into ws
  * (f32, M x N, zero on entry and zero again on exit), one more launch finalises (bias, activation, residual, bf16).
  * bf16 only, Cin % (64 ksplit) == 0; FS2_EINVAL for unsupported shapes (fall back to fs2_conv_gemm). */
@@ -100,7 +106,7 @@ int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, 
                uint64_t seed_post, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 /* d1 = dz (+ d1_add), d2 = dz * dropmask_pre * (relu_bwd ? z>0 : 1); dgamma/dbeta += column sums.
  * partial_ws: caller workspace of FS2_LN_BWD_GRID*2*C floats (per-block partial sums, reduced by a 2nd launch). */
-#define FS2_LN_BWD_GRID 512
+#define FS2_LN_BWD_GRID 1024
 int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
                const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
                float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, const uint64_t* seed_dev,
