@@ -37,17 +37,25 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <bool ONE_TAP> struct PCfg;
-// conv (taps >= 3): activation halo tile (256 + 16 rows) double-buffered per Cin chunk, weight ring of D slots
-template <> struct PCfg<false> {
-    static constexpr int D = 5, A_BYTES = 272 * 128, SCRATCH = 2 * 272 * 128, B_OFF = 2 * 272 * 128 + 1024, NJA = 9;
+template <bool ONE_TAP, bool WIDE> struct PCfg;
+// conv (taps >= 3), halo (taps-1)*dil <= 16 rows: activation halo tile (256 + 16 rows) double-buffered per Cin chunk, weight
+// ring of D = 5 slots
+template <> struct PCfg<false, false> {
+    static constexpr int D = 5, HALO = 16, A_BYTES = 272 * 128, SCRATCH = 2 * 272 * 128, B_OFF = 2 * 272 * 128 + 1024, NJA = 9;
+    static constexpr int AUX = B_OFF + D * 16384;
+};
+// conv with a WIDE halo, <= 64 rows (HiFi-GAN's dilated k = 7 / 11 convolutions: (k-1)*dil = 18 ... 50): 320-row halo tile,
+// weight ring of D = 4 slots
+template <> struct PCfg<false, true> {
+    static constexpr int D = 4, HALO = 64, A_BYTES = 320 * 128, SCRATCH = 2 * 320 * 128, B_OFF = 2 * 320 * 128 + 1024, NJA = 10;
     static constexpr int AUX = B_OFF + D * 16384;
 };
 // taps == 1: activation and weight tiles both in rings of D slots
-template <> struct PCfg<true> {
-    static constexpr int D = 3, A_BYTES = 256 * 128, SCRATCH = 0, B_OFF = 3 * 256 * 128, NJA = 8;
+template <> struct PCfg<true, false> {
+    static constexpr int D = 3, HALO = 0, A_BYTES = 256 * 128, SCRATCH = 0, B_OFF = 3 * 256 * 128, NJA = 8;
     static constexpr int AUX = B_OFF + D * 16384;
 };
+template <int N> __device__ __forceinline__ void p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 static constexpr int P_MAXB = 1024;                       // lens[] staged in LDS
 static constexpr int P_AUX_BYTES = P_MAXB * 4 + 4 * 512;  // lens + one 128-float bias line per consumer wave
 static constexpr int P_B_BYTES = 128 * 128;
@@ -103,10 +111,10 @@ __device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_li
 }
 
 // ------------------------------------------------------------------------------------------------ loader waves
-template <bool ONE_TAP>
+template <bool ONE_TAP, bool WIDE>
 __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int lw,
                                          unsigned mt_list, int ntiles) {
-    typedef PCfg<ONE_TAP> C;
+    typedef PCfg<ONE_TAP, WIDE> C;
     constexpr int D = C::D, NJA = C::NJA;
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(a.X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(a.W);
@@ -184,11 +192,11 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
         if (total - 1 - cs < D - 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (ONE_TAP) {
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                      // (D-2) x (8 A + 4 B), D = 3
+            p_wait_vm<(D - 2) * (NJA + 4)>();                                     // taps == 1: (D-2) x (8 A + 4 B)
         } else {
             const bool a_young = (ctap >= 1 && ctap <= D - 2) && (gc + 1 < nchunks);   // halo tile of chunk gc+1 issued after B(cs)
-            if (a_young) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");         // (D-2) x 4 B + 9 A, D = 5
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (a_young) p_wait_vm<(D - 2) * 4 + NJA>();                           // (D-2) x 4 B + the next chunk's halo tile
+            else p_wait_vm<(D - 2) * 4>();
         }
         __builtin_amdgcn_s_barrier();                        // publishes slot(cs); the consumers have left slot(cs-1)
         if (!ONE_TAP && ctap == 0 && gc + 1 < nchunks) {
@@ -357,11 +365,23 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, fl
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = o;
 }
 
-// ABL (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue
-template <bool ONE_TAP, int ABL>
+// leaky-ReLU on a landed activation fragment (HiFi-GAN's pre-activation convolutions; the LDS-DMA path cannot transform data on
+// its way in): widen both halves of each dword, max(x, slope x) (0 < slope < 1), hardware bf16 pack - 7 VALU per dword, two
+// fragments per k-slice of eight MFMAs
+__device__ __forceinline__ u32x4 p_lrelu(u32x4 v, float slope) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+        v[e] = pack_bf16x2(fmaxf(lo, lo * slope), fmaxf(hi, hi * slope));
+    }
+    return v;
+}
+
+// ABL bit 16 (shipped): leaky-ReLU prologue on the activation fragments.  Other ABL bits (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue
+template <bool ONE_TAP, bool WIDE, int ABL>
 __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int wm,
                                            unsigned mt_list, int ntiles, const int32_t* lens_s, float* bias_s) {
-    typedef PCfg<ONE_TAP> C;
+    typedef PCfg<ONE_TAP, WIDE> C;
     constexpr int D = C::D;
     const int nkc = sc.nkc_u;
     const int taps = ONE_TAP ? 1 : a.taps;
@@ -395,7 +415,8 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
     do {                                                                                                                    \
         u32x4 av0, av1;                                                                                                     \
         FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
-        av0 = Af[SET][0]; if (MASKED && !(LIVE0)) av0 = u32x4{0u, 0u, 0u, 0u};                                              \
+        av0 = Af[SET][0]; if (ABL & 16) av0 = p_lrelu(av0, a.in_slope);                                                     \
+        if (MASKED && !(LIVE0)) av0 = u32x4{0u, 0u, 0u, 0u};                                                                \
         FS2P_MFMA(SET, 0, 0, av0); FS2P_FENCE();                                                                            \
         const unsigned aa_ = (ABASE) + ((((AKEY)) ^ (unsigned)(JN)) << 4);                                                  \
         const unsigned ba_ = (BBASE) + ((ckb ^ (unsigned)(JN)) << 4);                                                       \
@@ -410,7 +431,8 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         FS2P_MFMA(SET, 0, 3, av0); FS2P_FENCE();                                                                            \
         if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][2], ba_, 8192); } FS2P_FENCE();                                            \
         FS2P_WAIT_LGKM(4); FS2P_FENCE();                                                                                    \
-        av1 = Af[SET][1]; if (MASKED && !(LIVE1)) av1 = u32x4{0u, 0u, 0u, 0u};                                              \
+        av1 = Af[SET][1]; if (ABL & 16) av1 = p_lrelu(av1, a.in_slope);                                                     \
+        if (MASKED && !(LIVE1)) av1 = u32x4{0u, 0u, 0u, 0u};                                                                \
         FS2P_MFMA(SET, 1, 0, av1); FS2P_FENCE();                                                                            \
         if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][3], ba_, 12288); } FS2P_FENCE();                                           \
         FS2P_MFMA(SET, 1, 1, av1); FS2P_FENCE();                                                                            \
@@ -514,10 +536,10 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
 #undef FS2P_MFMA
 }
 
-template <bool ONE_TAP, int ABL>
+template <bool ONE_TAP, bool WIDE, int ABL>
 __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSched sc0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef PCfg<ONE_TAP> C;
+    typedef PCfg<ONE_TAP, WIDE> C;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     PSched sc = sc0;
@@ -561,9 +583,9 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
         // the four consumer waves make the staged lengths visible to each other before anyone's epilogue: they all pass
         // the per-step barriers (>= 1) before the first epilogue, and LDS writes are ordered ahead of the wave's barrier
         // arrival by the s_waitcnt lgkmcnt(0) in front of the first barrier.
-        if (ntiles > 0) p_consumer<ONE_TAP, ABL>(a, sc, smem, lane, wave, load_mt_list(), ntiles, lens_s, bias_s);
+        if (ntiles > 0) p_consumer<ONE_TAP, WIDE, ABL>(a, sc, smem, lane, wave, load_mt_list(), ntiles, lens_s, bias_s);
     } else if (ntiles > 0) {                                 // (a workgroup without real tiles runs no barrier on either side)
-        p_loader<ONE_TAP>(a, sc, smem, lane, wave - 4, load_mt_list(), ntiles);
+        p_loader<ONE_TAP, WIDE>(a, sc, smem, lane, wave - 4, load_mt_list(), ntiles);
     }
 }
 
@@ -675,19 +697,20 @@ static int fs2_cu_count() {
     return cus[d];
 }
 
-template <bool ONE_TAP, int ABL>
+template <bool ONE_TAP, bool WIDE, int ABL>
 static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream) {
-    constexpr int dyn = PCfg<ONE_TAP>::AUX + P_AUX_BYTES;
+    constexpr int dyn = PCfg<ONE_TAP, WIDE>::AUX + P_AUX_BYTES;
     static Fs2DevOnce once;
-    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_p_kernel<ONE_TAP, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
-    conv_gemm_p_kernel<ONE_TAP, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_p_kernel<ONE_TAP, WIDE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
+    conv_gemm_p_kernel<ONE_TAP, WIDE, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
 }
 
 // Eligibility of the persistent kernel (pure function of the launch description; shared with fs2_conv_gemm_variant).
 bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks) {
-    if (dtype != FS2_BF16 || a.in_act != FS2_ACT_NONE) return false;
+    const bool inact = a.in_act == FS2_ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f;
+    if (dtype != FS2_BF16 || !(a.in_act == FS2_ACT_NONE || inact)) return false;
     const int taps = a.taps;
-    if (!(taps == 1 || (taps >= 3 && (taps - 1) * a.dil <= 16 && taps <= 32))) return false;
+    if (!(taps == 1 || (taps >= 3 && (taps - 1) * a.dil <= 64 && taps <= 32))) return false;
     if (a.Cin % 64 != 0 || !a.vec_ok || a.N % 8 != 0) return false;
     if ((double)a.M * a.ldx * 2 >= 2.0e9 || (double)a.N * taps * a.Cin * 2 >= 2.0e9) return false;
     const long tiles = (long)fs2_cdiv(a.M, 256) * fs2_cdiv(a.N, 128) * ks;
@@ -724,14 +747,21 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     (void)abl;
 #ifdef FS2_DEV
     switch (abl) {
-        case 1: if (taps == 1) launch_p<true, 1>(a, sc, stream); else launch_p<false, 1>(a, sc, stream); return;
-        case 2: if (taps == 1) launch_p<true, 2>(a, sc, stream); else launch_p<false, 2>(a, sc, stream); return;
-        case 3: if (taps == 1) launch_p<true, 3>(a, sc, stream); else launch_p<false, 3>(a, sc, stream); return;
-        case 4: if (taps == 1) launch_p<true, 4>(a, sc, stream); else launch_p<false, 4>(a, sc, stream); return;
+        case 1: if (taps == 1) launch_p<true, false, 1>(a, sc, stream); else launch_p<false, false, 1>(a, sc, stream); return;
+        case 2: if (taps == 1) launch_p<true, false, 2>(a, sc, stream); else launch_p<false, false, 2>(a, sc, stream); return;
+        case 3: if (taps == 1) launch_p<true, false, 3>(a, sc, stream); else launch_p<false, false, 3>(a, sc, stream); return;
+        case 4: if (taps == 1) launch_p<true, false, 4>(a, sc, stream); else launch_p<false, false, 4>(a, sc, stream); return;
         default: break;
     }
 #endif
-    if (taps == 1) launch_p<true, 0>(a, sc, stream); else launch_p<false, 0>(a, sc, stream);
+    const bool wide = taps > 1 && (taps - 1) * a.dil > 16;
+    if (a.in_act == FS2_ACT_LRELU) {
+        if (taps == 1) launch_p<true, false, 16>(a, sc, stream);
+        else if (wide) launch_p<false, true, 16>(a, sc, stream);
+        else launch_p<false, false, 16>(a, sc, stream);
+    } else if (taps == 1) launch_p<true, false, 0>(a, sc, stream);
+    else if (wide) launch_p<false, true, 0>(a, sc, stream);
+    else launch_p<false, false, 0>(a, sc, stream);
     if (ks > 1) {
         const long chunks = (long)a.M * (a.N >> 3);
         FS2_ACT_DISPATCH(a.act, (splitk_finalize_kernel<ACT><<<(unsigned)((chunks + 255) / 256), 256, 0, stream>>>(a, ws)));

@@ -113,6 +113,36 @@ def test_contraction_forward_and_dgrad_production_shapes(dev, dtype, name, Cin, 
     assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)) * valid, dtype, (name, "dgrad gate"))
 
 
+@pytest.mark.parametrize("name,C,N,k,dil,S,Bq", [("rb C256 k7 d3", 256, 256, 7, 3, 7200, 8), ("rb C128 k11 d5", 128, 128, 11, 5, 57600, 4),
+                                                 ("rb C128 k3 d1", 128, 128, 3, 1, 57600, 4), ("rb C256 k11 d1", 256, 256, 11, 1, 7200, 8),
+                                                 ("up0 as 3-tap", 512, 2048, 3, 1, 900, 8)])
+def test_vocoder_convs_with_leaky_relu_prologue(dev, name, C, N, k, dil, S, Bq):
+    """HiFi-GAN's pre-activation convolutions at batch-synthesis size (hifigan/models.py:96-103): leaky-ReLU prologue on the
+    input fragments, dilation halos of up to 50 rows (the persistent kernel's wide-halo configuration), leaky-ReLU epilogue and
+    the fused residual - elementwise against the exact-product reference."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(ord(c) for c in name))
+    M = Bq * S
+    pad = (k * dil - dil) // 2
+    x = torch.randn(M, C, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(N, k, C, generator=g) / math.sqrt(C * k)).to(dev).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(dev)
+    xa = torch.where(x.float() > 0, x.float(), (x.float() * 0.1)).to(torch.bfloat16)       # the prologue rounds lrelu(x) to bf16
+    xs = xa.float().view(Bq, S, C)
+    ref = torch.zeros(Bq, S, N, device=dev, dtype=torch.float64)
+    for j in range(k):
+        sh = j * dil - pad
+        lo, hi = max(0, -sh), min(S, S - sh)
+        ref[:, lo:hi] += (xs[:, lo + sh:hi + sh] @ w[:, j, :].float().t()).double()
+    ref = (ref + bias.double()).view(M, N)
+    y = ops.conv_gemm(x, w, bias, S, taps=k, dil=dil, pad=pad, in_act=ops.ACT_LRELU, in_slope=0.1, act=ops.ACT_LRELU, slope=0.1)
+    assert_rounding_only(y, torch.where(ref > 0, ref, ref * 0.1), torch.bfloat16, (name, "lrelu-conv-lrelu"))
+    if N == C:
+        res = torch.randn(M, N, generator=g).to(dev).to(torch.bfloat16)
+        y = ops.conv_gemm(x, w, bias, S, taps=k, dil=dil, pad=pad, in_act=ops.ACT_LRELU, in_slope=0.1, res=res, out_scale=1.0 / 3)
+        assert_rounding_only(y, (ref + res.double()) / 3, torch.bfloat16, (name, "lrelu-conv+res/3"))
+
+
 @pytest.mark.parametrize("ks", [2, 4])
 def test_splitk_contraction_matches_unsplit_reference(dev, ks):
     """the encoder's k=9 data gradient shape (M = 48 x 128, N = 256, K = 9 x 1024) through the K-split path: partial tiles added
