@@ -1541,9 +1541,15 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     // 8-wave tap-group kernels (one workgroup per CU): ONE round of <= 256 workgroups.  With two waves per SIMD a workgroup
     // no longer needs a successor queued behind it to hide its latencies, and every extra split is another full-tile burst
     // of atomics (r01k sweep: k=9 FFN 294 -> 250 us at 5 splits x 48 tiles, PostNet k=5 201 -> 158 us at 8 x 32).
-    int wg_target = units < 256 ? 192 : (NT == 1 ? 384 : (NW == 8 ? 256 : 768));
+    // r02 same-box A/B of the WHOLE step (tools/ab_env.py): these launches run on the side stream next to the data-gradient
+    // chain, and fewer, longer workgroups disturb it less than the split depth that is fastest in isolation (one-tap 384 ->
+    // 192, tap-group kernels 256 -> 128 workgroups: 10.16 -> 9.90 ms per step; 96 and below lose again)
+    int wg_target = units < 256 ? 192 : (NT == 1 ? 192 : (NW == 8 ? 128 : 768));
     int min_ups = NT == 1 ? 8 : ((tiles <= 8 && units >= 512) ? 16 : 4);
     if (wg_env) wg_target = wg_env;
+    static const int wg_env1 = fs2_dev_env("FS2_WGRAD_WGS1", 0), wg_env3 = fs2_dev_env("FS2_WGRAD_WGS3", 0);
+    if (NT == 1 && wg_env1) wg_target = wg_env1;
+    if (NT > 1 && wg_env3) wg_target = wg_env3;
     if (ups_env) min_ups = ups_env;
     long want = (NW == 8 && NT > 1) ? (wg_target / tiles) : (wg_target + tiles - 1) / tiles;   // floor: never spill into a second round
     if (want < 1) want = 1;
@@ -1579,7 +1585,12 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
     else if (dtype == FS2_BF16) {
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
         static const int wg_waves = fs2_dev_env("FS2_WGRAD_WAVES", 8);   // dev A/B: 4 | 8
-        if (fast && taps == 1) { launch_wgrad_bf16<1, 0, 4>(a, (lens && M % S == 0) ? S : M, 1, stream); bias_fused = true; }   // no taps, no lens: one "sequence" of M rows
+        static const int wg_waves1 = fs2_dev_env("FS2_WGRAD_WAVES1", 4);            // dev A/B: 4 | 8
+        if (fast && taps == 1) {
+            if (wg_waves1 == 8) launch_wgrad_bf16<1, 0, 8>(a, (lens && M % S == 0) ? S : M, 1, stream);
+            else launch_wgrad_bf16<1, 0, 4>(a, (lens && M % S == 0) ? S : M, 1, stream);
+            bias_fused = true;
+        }   // no taps, no lens: one "sequence" of M rows
         else if (fast && 2 * dil <= 8 && M % S == 0) {
             const int g3 = taps / 3, rem = taps - 3 * g3;
             if (wg_waves == 8) {

@@ -737,6 +737,8 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     sc.ntm = ntm; sc.ntn = ntn; sc.b = 0;
     sc.n_real = ntm; sc.n_pad = 0;
     sc.G = (int)((long)ntm * ntn * ks < cus ? (long)ntm * ntn * ks : cus);
+    static const int g_env = fs2_dev_env("FS2_P_G", 0);
+    if (g_env > 0 && g_env < sc.G) sc.G = g_env;
     const int taps = a.taps;
     static const int order_env = fs2_dev_env("FS2_P_ORDER", -1);
     // r02e same-box A/B: per-XCD N-fastest is faster wherever an M-tile has >= 2 N-tiles and the launch has at least two
