@@ -4,16 +4,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-// Development switches (ablations, forced variants, split-depth sweeps) exist only in -DFS2_DEV builds (`make dev` ->
-// libfs2hip_dev.so, loaded through FS2_LIB_PATH by the tools/ scripts).  In the shipped library every switch is a
-// compile-time constant: no environment variable can change what the product computes or skip work inside a timed region.
-#ifdef FS2_DEV
-static inline int fs2_dev_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-#define FS2_DEV_DBG(x) (x)
-#else
-#define fs2_dev_env(name, dflt) (dflt)
-#define FS2_DEV_DBG(x) false
-#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

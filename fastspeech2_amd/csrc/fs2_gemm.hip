@@ -1054,8 +1054,8 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
 
 // K-split form of fs2_conv_gemm for contractions with few output tiles and a long reduction (the encoder's k=9 data gradient:
 // 48 tiles x 144 K-steps on 256 CUs): `ksplit` workgroups share one output tile, each reduces a contiguous range of Cin
-// chunks and adds its partial tile into `ws` (f32, M x N, ZERO on entry, zero again on exit); one more launch applies bias /
-// activation / residual and writes Y.  Only shapes the persistent kernel takes (bf16, Cin % (64 ksplit) == 0, N % 8 == 0,
+// chunks and stores its partial tile into its own slab of `ws` (f32 scratch, ksplit x M x N, any contents); one more launch
+// sums the slabs, applies bias / activation / residual and writes Y.  Only shapes the persistent kernel takes (bf16, Cin % (64 ksplit) == 0, N % 8 == 0,
 // 16-byte rows, lens only together with tile_map); FS2_EINVAL otherwise - the caller falls back to fs2_conv_gemm.
 extern "C" int fs2_conv_gemm_splitk(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
                                     long ldy, const int32_t* lens, const int32_t* tile_map, float* ws, int ksplit, int M, int N,

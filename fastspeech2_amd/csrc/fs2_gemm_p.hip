@@ -66,8 +66,8 @@ struct PSched {
     int n_real, n_pad;         // real / padded M-tiles (read from the tile map on the device)
     const int32_t* tmap;       // [0] = n_real, [1 .. ntm] = real M-tiles then padded M-tiles; null = identity (no lens)
     int ks, nkc_u;             // K-splits per output tile (1 = none) and Cin chunks per unit (= Cin/64/ks).  ks > 1: every unit
-                               // adds its partial 256x128 tile into the f32 workspace `ws` (M x N, zero before the launch) and
-                               // splitk_finalize_kernel turns it into the bf16 output - for few-tile, long-reduction shapes
+                               // stores its partial 256x128 tile into its split's slab of the f32 workspace `ws` (ks x M x N) and
+                               // splitk_finalize_kernel sums the slabs into the bf16 output - for few-tile, long-reduction shapes
                                // (the encoder's k=9 data gradient: 48 tiles x 144 K-steps on 256 CUs)
     float* ws;
     int order;                 // 0: M-fastest over all workgroups (neighbours share the weight slice);
@@ -103,9 +103,10 @@ __device__ __forceinline__ int p_ntiles(const PSched& s) {
 
 // k-th unit of this workgroup -> (M-tile, N-tile, first Cin chunk); the M-tile ids of a workgroup's first 64 units sit in
 // `mt_list` (lane k)
-__device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_list, int& mt, int& nt, int& kc0) {
+__device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_list, int& mt, int& nt, int& kc0, int* split = nullptr) {
     int mi, sp;
     (void)p_unit(s, k, mi, nt, sp);
+    if (split) *split = __builtin_amdgcn_readfirstlane(sp);
     kc0 = __builtin_amdgcn_readfirstlane(sp * s.nkc_u);      // wave-uniform by construction; tell the compiler (SGPR operand of the DMA)
     mt = s.tmap ? (int)__builtin_amdgcn_readlane(mt_list, k) : mi;
 }
@@ -295,9 +296,11 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
     }
 }
 
-// K-split epilogue: the partial tile is ADDED into the f32 workspace (hardware float atomics; same lane layout as above: after
-// the half-wave swap a lane holds 2 x 8 consecutive columns of one row).  Bias / activation / residual happen once, in
-// splitk_finalize_kernel.
+// K-split epilogue: the partial tile goes into this split's own f32 slab of the workspace with plain 16-byte stores (same lane
+// layout as above: after the half-wave swap a lane holds 2 x 8 consecutive columns of one row).  The first version ADDED it
+// into one shared M x N slab with float atomics: a lane owns a ROW there, so every atomic instruction touched 64 different
+// cache lines (r02f: 48 tiles x 144 K-steps ran 100 us unsplit, 131 us at 2 splits, 185 us at 4).  Bias / activation /
+// residual happen once, in splitk_finalize_kernel, which also sums the slabs.
 __device__ __forceinline__ void p_epilogue_splitk(const ConvGemmArgs& a, float* ws, f32x16 (&acc)[2][4], int m0, int n0, int wm,
                                                   int fl, int fh) {
 #pragma unroll
@@ -319,26 +322,29 @@ __device__ __forceinline__ void p_epilogue_splitk(const ConvGemmArgs& a, float* 
             for (int ch = 0; ch < 2; ++ch) {
                 const int n = n0 + nb * 32 + ch * 16 + fh * 8;
                 if (n >= a.N) continue;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) unsafeAtomicAdd(wrow + n + e, c[ch][e]);
+                *reinterpret_cast<float4*>(wrow + n) = make_float4(c[ch][0], c[ch][1], c[ch][2], c[ch][3]);
+                *reinterpret_cast<float4*>(wrow + n + 4) = make_float4(c[ch][4], c[ch][5], c[ch][6], c[ch][7]);
             }
         }
     }
 }
 
-// ws (f32, M x N) -> Y: bias, activation, residual / gate, scale, padded-row zero, bf16; ws is CLEARED on the way (the caller
-// zeroes it once when it allocates it; every launch leaves it zero again).  One thread = 8 consecutive columns of one row.
+// ws (f32, ks slabs of M x N) -> Y: slab sum, bias, activation, residual / gate, scale, padded-row zero, bf16.  One thread = 8
+// consecutive columns of one row.  Rows of M-tiles the tile map removed were written by nobody: they are padded rows and come
+// out as zeros whatever the slabs hold.
 template <int ACT>
-__global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, float* __restrict__ ws) {
+__global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, const float* __restrict__ ws, int ks) {
     const int cpr = a.N >> 3;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)a.M * cpr) return;
     const int m = (int)(idx / cpr), n = (int)(idx - (long)m * cpr) * 8;
-    float* wp = ws + (size_t)m * a.N + n;
-    const float4 x0 = *reinterpret_cast<const float4*>(wp), x1 = *reinterpret_cast<const float4*>(wp + 4);
-    *reinterpret_cast<float4*>(wp) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(wp + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    const float* wp = ws + (size_t)m * a.N + n;
+    const size_t slab = (size_t)a.M * a.N;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < ks; ++sp) {
+        const float4 x0 = *reinterpret_cast<const float4*>(wp + sp * slab), x1 = *reinterpret_cast<const float4*>(wp + sp * slab + 4);
+        v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+    }
     if (a.bias) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += a.bias[n + e];
@@ -454,7 +460,8 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
     }
     for (int k = 0; k < ntiles; ++k) {
         int mt, nt, kc0_unused;
-        p_tile_of(sc, k, mt_list, mt, nt, kc0_unused);
+        int split;
+        p_tile_of(sc, k, mt_list, mt, nt, kc0_unused, &split);
         const int m0 = mt * 256, n0 = nt * 128;
         // tap-validity bits of this lane's two rows (bit j: tap j stays inside the row's own sequence)
         unsigned vmask[2] = {0xffffffffu, 0xffffffffu};
@@ -519,7 +526,7 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
 
         if (sc.ks > 1) {
-            p_epilogue_splitk(a, sc.ws, acc, m0, n0, wm, fl, fh);
+            p_epilogue_splitk(a, sc.ws + (size_t)split * a.M * a.N, acc, m0, n0, wm, fl, fh);
         } else if (!(ABL & 4)) {
             FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wm, fl, fh, lens_s, bias_s, lane)));
         } else {
@@ -766,6 +773,6 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     else launch_p<false, false, 0>(a, sc, stream);
     if (ks > 1) {
         const long chunks = (long)a.M * (a.N >> 3);
-        FS2_ACT_DISPATCH(a.act, (splitk_finalize_kernel<ACT><<<(unsigned)((chunks + 255) / 256), 256, 0, stream>>>(a, ws)));
+        FS2_ACT_DISPATCH(a.act, (splitk_finalize_kernel<ACT><<<(unsigned)((chunks + 255) / 256), 256, 0, stream>>>(a, ws, ks)));
     }
 }

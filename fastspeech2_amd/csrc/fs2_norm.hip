@@ -96,6 +96,109 @@ __global__ void ln_fwd_kernel(LnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- C = 256, bf16: the transformer's LayerNorm shape
+// r02i ISA of the generic kernel: one 8-byte load per lane and row, y waited for before the residual load is even issued,
+// then twelve ds_bpermute_b32 (LDS crossbar, each individually waited) for the two wave sums, then lens, then gamma/beta -
+// five dependent memory round trips per row with at most 512 B per wave in flight (2.6-3.1 TB/s).  Here HALF a wave owns a
+// row (32 lanes x 16 B), a wave owns 2 RP rows whose loads (y, residual, gamma, beta, lens) are all issued before the first
+// use, and the row sums run on DPP (quad_perm, row_half_mirror, row_mirror) plus ONE cross-row permute.
+#define FS2_DPP(v, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, true))
+__device__ __forceinline__ float half_sum32(float v) {          // sum over each 32-lane half, result in every lane of the half
+    v += FS2_DPP(v, 0xB1);      // quad_perm [1,0,3,2]
+    v += FS2_DPP(v, 0x4E);      // quad_perm [2,3,0,1]
+    v += FS2_DPP(v, 0x141);     // row_half_mirror: lane i <-> 7 - i of its group of 8
+    v += FS2_DPP(v, 0x140);     // row_mirror: lane i <-> 15 - i of its row of 16
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8f(const float* f) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
+template <int RP>
+__global__ void __launch_bounds__(256) ln_fwd_c256_bf16_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63, hl = lane & 31, hh = lane >> 5;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * RP) + hh;
+    const int c = hl * 8;
+    bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
+    const bf16_t* res = reinterpret_cast<const bf16_t*>(a.res);
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+    if (a.seed_dev) { uint64_t o = *a.seed_dev; a.seed_pre += o; a.seed_post += o; }
+    uint4 qy[RP], qr[RP];
+    int len[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int row = min(row0 + 2 * i, a.rows - 1);
+        qy[i] = *reinterpret_cast<const uint4*>(y + (size_t)row * 256 + c);
+        len[i] = a.S;
+    }
+    if (res) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) qr[i] = *reinterpret_cast<const uint4*>(res + (size_t)min(row0 + 2 * i, a.rows - 1) * 256 + c);
+    }
+    if (a.lens) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) len[i] = a.lens[min(row0 + 2 * i, a.rows - 1) / a.S];
+    }
+    const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c), g1 = *reinterpret_cast<const float4*>(a.gamma + c + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(a.beta + c), b1 = *reinterpret_cast<const float4*>(a.beta + c + 4);
+    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float ik_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+    const float ik_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int row = row0 + 2 * i;
+        const bool ok = row < a.rows;
+        const uint32_t e = (uint32_t)row * 256u + (uint32_t)c;
+        float x[8];
+        unpack8(qy[i], x);
+        if (a.p_pre > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] *= fs2_drop_scale(a.seed_pre, e + j, a.p_pre, ik_pre);
+        }
+        if (res) {
+            float r[8];
+            unpack8(qr[i], r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] += r[j];
+        }
+        if (res || a.p_pre > 0.f) {
+            const uint4 z = pack8f(x);
+            if (ok) *reinterpret_cast<uint4*>(y + (size_t)row * 256 + c) = z;
+            unpack8(z, x);                       // statistics on the values as stored: backward sees the same z
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j];
+        const float mean = half_sum32(s) * (1.f / 256.f);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = x[j] - mean; sq += d * d; }
+        const float rstd = rsqrtf(half_sum32(sq) * (1.f / 256.f) + a.eps);
+        if (hl == 0 && ok) { a.mean[row] = mean; a.rstd[row] = rstd; }
+        const bool pad = a.lens && (row - (row / a.S) * a.S) >= len[i];
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (x[j] - mean) * rstd * gm[j] + bt[j];
+        if (a.p_post > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= fs2_drop_scale(a.seed_post, e + j, a.p_post, ik_post);
+        }
+        if (pad) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        }
+        if (ok) *reinterpret_cast<uint4*>(out + (size_t)row * 256 + c) = pack8f(o);
+    }
+}
+
 extern "C" int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, const int32_t* lens, void* out,
                           float* mean, float* rstd, int B, int S, int C, float eps, float p_pre, uint64_t seed_pre,
                           float p_post, uint64_t seed_post, const uint64_t* seed_dev, int dtype, hipStream_t stream) {
@@ -107,6 +210,12 @@ extern "C" int fs2_ln_fwd(void* y, const void* res, const float* gamma, const fl
     a.rows = B * S; a.S = S; a.C = C; a.eps = eps; a.p_pre = p_pre; a.p_post = p_post; a.seed_pre = seed_pre; a.seed_post = seed_post;
     a.seed_dev = seed_dev;
     if (a.rows == 0) return FS2_OK;
+    static const int ln_fast = fs2_dev_env("FS2_LN_FAST", 3);       // dev A/B only: bit 0 forward, bit 1 backward
+    if ((ln_fast & 1) && dtype == FS2_BF16 && C == 256 && (((uintptr_t)y | (uintptr_t)res | (uintptr_t)out) & 15) == 0) {
+        ln_fwd_c256_bf16_kernel<2><<<fs2_cdiv(a.rows, 16), 256, 0, stream>>>(a);
+        FS2_CHECK_LAUNCH("ln_fwd");
+        return FS2_OK;
+    }
     const int nv = C <= 256 ? 1 : (C <= 512 ? 2 : (C <= 1024 ? 4 : 8));
 #define LN_FWD_LAUNCH(TT, NVV) ln_fwd_kernel<TT, NVV><<<fs2_cdiv(a.rows, 4), 256, 0, stream>>>(a)
 #define LN_FWD_NV(TT) do { if (nv == 1) LN_FWD_LAUNCH(TT, 1); else if (nv == 2) LN_FWD_LAUNCH(TT, 2); else if (nv == 4) LN_FWD_LAUNCH(TT, 4); else LN_FWD_LAUNCH(TT, 8); } while (0)
@@ -243,6 +352,113 @@ __global__ void __launch_bounds__(512) ln_bwd_kernel(LnBwdArgs a) {
     }
 }
 
+// C = 256, bf16 backward: half a wave per row with 16-byte lanes (as ln_fwd_c256_bf16_kernel), and the NEXT row pair's loads
+// (z, dout, d1_add, mean, rstd, lens) are issued before the current pair is reduced and stored, so every wave keeps a full
+// set of loads in flight across its whole row loop.  The host sizes the grid so that all waves run the same number of
+// iterations (44400 rows: 925 workgroups x 3 instead of 1024 x 2.7).
+struct LnBwdRow { uint4 z, g, r; float mean, rstd; int len; };
+__device__ __forceinline__ void ln_bwd_c256_load(const LnBwdArgs& a, int row, int c, LnBwdRow& q) {
+    const int rc = min(row, a.rows - 1);
+    q.z = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.z) + (size_t)rc * 256 + c);
+    q.g = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.dout) + (size_t)rc * 256 + c);
+    if (a.d1 && a.d1_add) q.r = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.d1_add) + (size_t)rc * 256 + c);
+    q.mean = a.mean[rc]; q.rstd = a.rstd[rc];
+    q.len = a.lens ? a.lens[rc / a.S] : a.S;
+}
+
+__global__ void __launch_bounds__(512) ln_bwd_c256_bf16_kernel(LnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_red[16][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hl = lane & 31, hh = lane >> 5;
+    const int c = hl * 8;
+    float ag[8], ab[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+    const float ik_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+    const float ik_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+    if (a.seed_dev) { uint64_t o = *a.seed_dev; a.seed_pre += o; a.seed_post += o; }
+    const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c), g1 = *reinterpret_cast<const float4*>(a.gamma + c + 4);
+    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const int stride = gridDim.x * 16;
+    int row = (blockIdx.x * 8 + w) * 2 + hh;
+    LnBwdRow nx;
+    nx.r = make_uint4(0, 0, 0, 0);
+    ln_bwd_c256_load(a, row, c, nx);
+    for (; row - hh < a.rows; row += stride) {
+        const LnBwdRow q = nx;
+        if (row - hh + stride < a.rows) ln_bwd_c256_load(a, row + stride, c, nx);     // wave-uniform condition
+        const bool ok = row < a.rows;
+        const bool live = ok && (row - (row / a.S) * a.S) < q.len;                     // padded rows: g = 0
+        const uint32_t e = (uint32_t)row * 256u + (uint32_t)c;
+        float z[8], g[8], x[8];
+        unpack8(q.z, z);
+        unpack8(q.g, g);
+        if (a.p_post > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] *= fs2_drop_scale(a.seed_post, e + j, a.p_post, ik_post);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (!live) g[j] = 0.f;
+            x[j] = (z[j] - q.mean) * q.rstd;
+            ag[j] += g[j] * x[j];
+            ab[j] += g[j];
+            g[j] *= gm[j];
+            s1 += g[j];
+            s2 += g[j] * x[j];
+        }
+        s1 = half_sum32(s1) * (1.f / 256.f);
+        s2 = half_sum32(s2) * (1.f / 256.f);
+        float dz[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[j] = q.rstd * (g[j] - s1 - x[j] * s2);
+        if (a.d1) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = dz[j];
+            if (a.d1_add) {
+                float r[8];
+                unpack8(q.r, r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += r[j];
+            }
+            if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.d1) + (size_t)row * 256 + c) = pack8f(o);
+        }
+        if (a.d2) {
+            if (a.p_pre > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dz[j] *= fs2_drop_scale(a.seed_pre, e + j, a.p_pre, ik_pre);
+            }
+            if (a.relu_bwd) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (!(z[j] > 0.f)) dz[j] = 0.f;
+            }
+            if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.d2) + (size_t)row * 256 + c) = pack8f(dz);
+        }
+    }
+    // dgamma / dbeta partials of the workgroup: 16 half-waves -> LDS -> one column per thread -> partial[block][2][256]
+    const int hw = w * 2 + hh;
+    *reinterpret_cast<float4*>(&s_red[hw][c]) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+    *reinterpret_cast<float4*>(&s_red[hw][c + 4]) = make_float4(ag[4], ag[5], ag[6], ag[7]);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_red[k][threadIdx.x];
+        a.partial[((size_t)blockIdx.x * 2) * 256 + threadIdx.x] = t;
+    }
+    __syncthreads();
+    *reinterpret_cast<float4*>(&s_red[hw][c]) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+    *reinterpret_cast<float4*>(&s_red[hw][c + 4]) = make_float4(ab[4], ab[5], ab[6], ab[7]);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_red[k][threadIdx.x];
+        a.partial[((size_t)blockIdx.x * 2 + 1) * 256 + threadIdx.x] = t;
+    }
+}
+
 // sums the per-block partials [nblocks][2C]: grid (ceil(2C/256), row-groups); every thread owns one column and walks
 // its row-group with independent (unrolled) coalesced loads, then one atomic per column and row-group (<= 32-way).
 // (r01h: the first version walked all 1024 partial rows with 16 blocks and cost a flat 21 us per LayerNorm.)
@@ -282,6 +498,16 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     if (a.rows == 0) return FS2_OK;
     int grid = fs2_cdiv(a.rows, 8);
     if (grid > FS2_LN_BWD_GRID) grid = FS2_LN_BWD_GRID;
+    const bool al16 = ((((uintptr_t)z | (uintptr_t)dout | (uintptr_t)d1_add | (uintptr_t)d1 | (uintptr_t)d2) & 15) == 0);
+    static const int ln_fast = fs2_dev_env("FS2_LN_FAST", 3);
+    if ((ln_fast & 2) && dtype == FS2_BF16 && C == 256 && al16) {
+        const int iters = fs2_cdiv(a.rows, 16 * FS2_LN_BWD_GRID);        // same trip count for every wave
+        grid = fs2_cdiv(a.rows, 16 * iters);
+        ln_bwd_c256_bf16_kernel<<<grid, 512, 0, stream>>>(a);
+        ln_bwd_reduce_kernel<<<dim3(fs2_cdiv(2 * C, 256), 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
+        FS2_CHECK_LAUNCH("ln_bwd");
+        return FS2_OK;
+    }
     const int nv = C <= 256 ? 1 : (C <= 512 ? 2 : (C <= 1024 ? 4 : 8));
 #define LN_BWD_LAUNCH(TT, NVV) ln_bwd_kernel<TT, NVV><<<grid, 512, 0, stream>>>(a)
 #define LN_BWD_NV(TT) do { if (nv == 1) LN_BWD_LAUNCH(TT, 1); else if (nv == 2) LN_BWD_LAUNCH(TT, 2); else if (nv == 4) LN_BWD_LAUNCH(TT, 4); else LN_BWD_LAUNCH(TT, 8); } while (0)
@@ -324,27 +550,39 @@ __device__ __forceinline__ float fs2_tanh(float x) {
 // Reducing modes (0, 2) run FEW fat workgroups (NT = 1024 threads, 4 rows in flight per thread): every workgroup ends with
 // 2C same-address atomics that all land on the same ~32 cache lines, so their number - not the streaming - sets the time
 // (1024 workgroups: 103-118 us per pass; ~100: the HBM time).  Streaming modes (1, 3) use many 256-thread workgroups.
-template <typename T, int MODE, int NT>
+// V = channels per thread: 4 (8 / 16 bytes per access) or, for bf16 with C % 8 == 0, 8 (16-byte lanes: r02 PMC showed the
+// 8-byte version streaming at 1.5-3.5 TB/s with the per-thread bytes in flight as the limiter).
+template <typename T, int V> __device__ __forceinline__ void bn_ldv(const T* p, float* f) {
+    if constexpr (V == 8) { unpack8(*reinterpret_cast<const uint4*>(p), f); }
+    else { float4 t = ld4<T>(p); f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w; }
+}
+template <typename T, int V> __device__ __forceinline__ void bn_stv(T* p, const float* f) {
+    if constexpr (V == 8) { *reinterpret_cast<uint4*>(p) = pack8f(f); }
+    else st4<T>(p, make_float4(f[0], f[1], f[2], f[3]));
+}
+
+template <typename T, int MODE, int NT, int V>
 __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
-    __shared__ float s_red[2][NT * 4];
+    __shared__ float s_red[NT * V];
     const T* x = reinterpret_cast<const T*>(a.x);
     const T* dout = reinterpret_cast<const T*>(a.dout);
     const T* res = reinterpret_cast<const T*>(a.res);
     T* out = reinterpret_cast<T*>(a.out);
     const int chunk = threadIdx.x & (a.cprp - 1), rl = threadIdx.x / a.cprp, nrl = NT / a.cprp;
-    const int c = chunk * 4;
+    const int c = chunk * V;
     const bool cok = c < a.C;
     uint64_t seed = a.seed;
     if (a.seed_dev) seed += *a.seed_dev;
     const float ik = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-    float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, gm[4] = {0, 0, 0, 0}, bt[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+    float mu[V], rs[V], gm[V], bt[V], m1[V], m2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { mu[k] = 0.f; rs[k] = 0.f; gm[k] = 0.f; bt[k] = 0.f; m1[k] = 0.f; m2[k] = 0.f; }
     if (cok) {
         if (MODE == 0) {
-            float4 s0 = ld4<T>(x + c);
-            mu[0] = s0.x; mu[1] = s0.y; mu[2] = s0.z; mu[3] = s0.w;
+            bn_ldv<T, V>(x + c, mu);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < V; ++k) {
                 mu[k] = a.mean_rstd[c + k]; rs[k] = a.mean_rstd[a.C + c + k]; gm[k] = a.gamma[c + k]; bt[k] = a.beta[c + k];
                 if (MODE == 3) { m1[k] = a.sums[c + k] / (float)a.M; m2[k] = a.sums[a.C + c + k] / (float)a.M; }
             }
@@ -354,33 +592,38 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
         // the reduced sums ARE the affine gradients (sum g = dbeta, sum g*xhat = dgamma): workgroup 0 adds them into the
         // parameter-gradient buffers and clears the workspace the next call reduces into (ping-pong: nobody reads that one now)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             if (a.acc_dbeta) { a.acc_dbeta[c + k] += a.sums[c + k]; a.acc_dgamma[c + k] += a.sums[a.C + c + k]; }
             if (a.clear) { a.clear[c + k] = 0.f; a.clear[a.C + c + k] = 0.f; }
         }
     }
-    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    float a1[V], a2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { a1[k] = 0.f; a2[k] = 0.f; }
     const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
-    auto row = [&](int r, float4 v4, float4 g4) {
+    auto row = [&](int r, float* v, const float* g) {
         const size_t e = (size_t)r * a.C + c;
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
         if (MODE == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { float d = v[k] - mu[k]; a1[k] += d; a2[k] += d * d; }
+            for (int k = 0; k < V; ++k) { float d = v[k] - mu[k]; a1[k] += d; a2[k] += d * d; }
         } else if (MODE == 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < V; ++k) {
                 float o = (v[k] - mu[k]) * rs[k] * gm[k] + bt[k];
                 if (a.act == FS2_ACT_TANH) o = fs2_tanh(o);
                 if (a.p > 0.f) o *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
                 v[k] = o;
             }
-            if (res) { float4 r4 = ld4<T>(res + e); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-            st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
-        } else {
-            float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            if (res) {
+                float r4[V];
+                bn_ldv<T, V>(res + e, r4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < V; ++k) v[k] += r4[k];
+            }
+            bn_stv<T, V>(out + e, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
                 float xh = (v[k] - mu[k]) * rs[k];
                 float gg = g[k];
                 if (a.p > 0.f) gg *= fs2_drop_scale(seed, (uint32_t)(e + k), a.p, ik);
@@ -388,39 +631,43 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
                 if (MODE == 2) { a1[k] += gg; a2[k] += gg * xh; }
                 else v[k] = gm[k] * rs[k] * (gg - m1[k] - xh * m2[k]);
             }
-            if (MODE == 3) st4<T>(out + e, make_float4(v[0], v[1], v[2], v[3]));
+            if (MODE == 3) bn_stv<T, V>(out + e, v);
         }
     };
     if (cok) {
         constexpr int U = (MODE == 0 || MODE == 2) ? 4 : 2;       // rows in flight per thread
         int r = r0 + rl;
         for (; r + (U - 1) * nrl < r1; r += U * nrl) {
-            float4 vv[U], gg[U];
+            float vv[U][V], gg[U][V];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                vv[u] = ld4<T>(x + (size_t)(r + u * nrl) * a.C + c);
-                if (MODE >= 2) gg[u] = ld4<T>(dout + (size_t)(r + u * nrl) * a.C + c); else gg[u] = vv[u];
+                bn_ldv<T, V>(x + (size_t)(r + u * nrl) * a.C + c, vv[u]);
+                if (MODE >= 2) bn_ldv<T, V>(dout + (size_t)(r + u * nrl) * a.C + c, gg[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) row(r + u * nrl, vv[u], gg[u]);
         }
         for (; r < r1; r += nrl) {
-            float4 v4 = ld4<T>(x + (size_t)r * a.C + c);
-            float4 g4 = MODE >= 2 ? ld4<T>(dout + (size_t)r * a.C + c) : v4;
-            row(r, v4, g4);
+            float v1[V], g1[V];
+            bn_ldv<T, V>(x + (size_t)r * a.C + c, v1);
+            if (MODE >= 2) bn_ldv<T, V>(dout + (size_t)r * a.C + c, g1);
+            row(r, v1, g1);
         }
     }
     if (MODE == 0 || MODE == 2) {                      // reduce over the block's row lanes, then one atomic per channel
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s_red[0][threadIdx.x * 4 + k] = a1[k]; s_red[1][threadIdx.x * 4 + k] = a2[k]; }
-        __syncthreads();
-        if (rl == 0 && cok) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float t1 = 0.f, t2 = 0.f;
-                for (int j = 0; j < nrl; ++j) { t1 += s_red[0][(j * a.cprp + chunk) * 4 + k]; t2 += s_red[1][(j * a.cprp + chunk) * 4 + k]; }
-                atomicAdd(a.sums + c + k, t1);
-                atomicAdd(a.sums + a.C + c + k, t2);
+            for (int k = 0; k < V; ++k) s_red[threadIdx.x * V + k] = pass ? a2[k] : a1[k];
+            __syncthreads();
+            if (rl == 0 && cok) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    float t = 0.f;
+                    for (int j = 0; j < nrl; ++j) t += s_red[(j * a.cprp + chunk) * V + k];
+                    atomicAdd(a.sums + (pass ? a.C : 0) + c + k, t);
+                }
             }
         }
     }
@@ -436,8 +683,14 @@ __global__ void bn_stats_fix_kernel(const T* __restrict__ x, float* __restrict__
     stats[C + c] = fmaxf(s2 - s1 * s1 / (float)M, 0.f);
 }
 
-static int bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks) {
-    int cpr = C / 4, cprp = 1;
+static int bn_vec(const BnArgs& a, int C, int dtype) {     // channels per thread: 8 when every bf16 row chunk is 16-byte addressable
+    const uintptr_t al = (uintptr_t)a.x | (uintptr_t)a.dout | (uintptr_t)a.res | (uintptr_t)a.out;
+    static const int vec_env = fs2_dev_env("FS2_BN_VEC", 8);       // dev A/B only
+    if (vec_env == 4) return 4;
+    return (dtype == FS2_BF16 && C % 8 == 0 && (al & 15) == 0) ? 8 : 4;
+}
+static int bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks, int vec) {
+    int cpr = C / vec, cprp = 1;
     while (cprp < cpr) cprp <<= 1;
     a.cprp = cprp;
     a.M = M; a.C = C;
@@ -450,8 +703,9 @@ static int bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks) {
     return fs2_cdiv(M, rpb);
 }
 #define BN_LAUNCH(MODE, NT, grid) do { \
-    if (dtype == FS2_F32) bn_rows_kernel<float, MODE, NT><<<grid, NT, 0, stream>>>(a); \
-    else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE, NT><<<grid, NT, 0, stream>>>(a); \
+    if (dtype == FS2_F32) bn_rows_kernel<float, MODE, NT, 4><<<grid, NT, 0, stream>>>(a); \
+    else if (dtype == FS2_BF16 && vec == 8) bn_rows_kernel<bf16_t, MODE, NT, 8><<<grid, NT, 0, stream>>>(a); \
+    else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE, NT, 4><<<grid, NT, 0, stream>>>(a); \
     else { fs2_set_error("bn: dtype"); return FS2_EDTYPE; } } while (0)
 #define BN_REDUCE_BLOCKS 96        /* statistics: pure streaming, atomics-bound */
 #define BN_BWD1_BLOCKS 256         /* backward sums: tanh + dropout hash per element -> needs every CU */
@@ -462,7 +716,8 @@ extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
     a.x = x; a.sums = stats;
-    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS);
+    const int vec = bn_vec(a, C, dtype);
+    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec);
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
     else bn_stats_fix_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats, M, C);
@@ -517,7 +772,8 @@ extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, float* running
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_train_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
     a.x = x; a.sums = stats_ws;
-    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS);
+    const int vec = bn_vec(a, C, dtype);
+    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec);
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
     else bn_fix_finalize_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
@@ -543,7 +799,8 @@ extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* 
     BnArgs a = {};
     a.x = x; a.res = res; a.out = out; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.act = act; a.p = p;
     a.seed = seed; a.seed_dev = seed_dev;
-    int grid = bn_geometry(a, M, C, 256, 2048);
+    const int vec = bn_vec(a, C, dtype);
+    int grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(1, 256, grid);
     FS2_CHECK_LAUNCH("bn_apply");
     return FS2_OK;
@@ -561,9 +818,10 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     BnArgs a = {};
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
-    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS);
+    const int vec = bn_vec(a, C, dtype);
+    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec);
     BN_LAUNCH(2, 1024, grid);
-    grid = bn_geometry(a, M, C, 256, 2048);
+    grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(3, 256, grid);
     FS2_CHECK_LAUNCH("bn_bwd");
     return FS2_OK;
@@ -580,10 +838,11 @@ extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean
     BnArgs a = {};
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
-    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS);
+    const int vec = bn_vec(a, C, dtype);
+    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec);
     BN_LAUNCH(2, 1024, grid);
     a.acc_dbeta = dbeta_acc; a.acc_dgamma = dgamma_acc; a.clear = sums_next;
-    grid = bn_geometry(a, M, C, 256, 2048);
+    grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(3, 256, grid);
     FS2_CHECK_LAUNCH("bn_bwd_acc");
     return FS2_OK;

@@ -251,10 +251,10 @@ class Engine:
         M, N, Cin = dy.shape[0], wd.shape[0], wd.shape[-1]
         ks = ops.splitk_for(M, N, Cin, taps, dy.dtype) if (lens is None or self._tmap(lens) is not None) else 1
         ws = None
-        if ks > 1:                                  # persistent zero workspace (the finalize launch clears it again)
-            ws = self._splitk_ws.get((M, N))
+        if ks > 1:                                  # persistent f32 scratch: one M x N slab per split
+            ws = self._splitk_ws.get((ks, M, N))
             if ws is None:
-                ws = self._splitk_ws[(M, N)] = torch.zeros(M, N, device=dy.device, dtype=torch.float32)
+                ws = self._splitk_ws[(ks, M, N)] = torch.empty(ks, M, N, device=dy.device, dtype=torch.float32)
         return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens, tmap=self._tmap(lens),
                              ksplit=ks, ws=ws)
 

@@ -110,8 +110,8 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if ksplit > 1:      # few output tiles, long reduction: K-split workgroups + f32 workspace (zero between calls) + finalize launch
-        assert ws is not None and ws.numel() >= M * N and in_act == ACT_NONE and not accumulate
+    if ksplit > 1:      # few output tiles, long reduction: K-split workgroups + f32 scratch slabs (ksplit x M x N) + finalize launch
+        assert ws is not None and ws.numel() >= ksplit * M * N and ws.dtype == torch.float32 and in_act == ACT_NONE and not accumulate
         _lib.call("fs2_conv_gemm_splitk", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), _p(ws),
                   ksplit, M, N, Cin, S, taps, dil, pad, act, slope, out_scale, dt(x), _stream())
     else:
@@ -127,13 +127,23 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
 
 
 def splitk_for(M, N, Cin, taps, dtype):
-    """K-split depth the engine uses for a contraction.  Always 1: measured (r02f, encoder k=9 data gradient, 48 output tiles x
-    144 K-steps) the f32-atomic partial tiles cost more than the idle CUs they fill - unsplit persistent kernel 100 us,
-    ksplit 2: 131 us, ksplit 4: 185 us (the 128^2 kernel with in-workgroup split: 115 us).  fs2_conv_gemm_splitk stays in the
-    ABI (tested) for shapes where that balance differs."""
+    """K-split depth the engine uses for a contraction: 1 unless the persistent kernel would run fewer than a quarter of the CUs'
+    worth of 256x128 tiles over a long reduction (>= 96 K-steps of 64) - the encoder's k=9 data gradient, 48 tiles x 144 steps.
+    Then the largest of 4 / 2 that divides the Cin chunks.  (r02f measured the first version - partial tiles ADDED into one
+    slab with row-per-lane float atomics - slower than not splitting: 100 us unsplit, 131 us at 2, 185 us at 4; the partial
+    tiles now go to per-split slabs with plain stores.)"""
+    if dtype != torch.bfloat16 or Cin % 64 or N % 8:
+        return 1
+    tiles = -(-M // TILE_ROWS) * -(-N // 128)
+    if tiles * 4 > CU_COUNT or taps * (Cin // 64) < 96:
+        return 1
+    for ks in (4, 2):
+        if (Cin // 64) % ks == 0 and tiles * ks <= CU_COUNT:
+            return ks
     return 1
 
 
+CU_COUNT = 256       # MI355X
 TILE_ROWS = 256      # M-tile height of the persistent contraction kernel (fs2_gemm_p.hip)
 
 

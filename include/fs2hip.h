@@ -57,8 +57,8 @@ int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, fs2_
  * (optional). */
 int fs2_lens_prep(const int64_t* lens, int B, int S, int rows, int32_t* lens32, void* mask, float* count, int32_t* tile_map,
                   fs2_stream_t stream);
-/* K-split form for few-tile, long-reduction contractions: `ksplit` workgroups per output tile add partial tiles into ws
- * (f32, M x N, zero on entry and zero again on exit), one more launch finalises (bias, activation, residual, bf16).
+/* K-split form for few-tile, long-reduction contractions: `ksplit` workgroups per output tile store partial tiles into ws
+ * (f32 scratch, ksplit x M x N, any contents), one more launch sums them and finalises (bias, activation, residual, bf16).
  * bf16 only, Cin % (64 ksplit) == 0; FS2_EINVAL for unsupported shapes (fall back to fs2_conv_gemm). */
 int fs2_conv_gemm_splitk(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Y,
                          long ldy, const int32_t* lens, const int32_t* tile_map, float* ws, int ksplit, int M, int N, int Cin,

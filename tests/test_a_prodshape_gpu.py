@@ -145,8 +145,8 @@ def test_vocoder_convs_with_leaky_relu_prologue(dev, name, C, N, k, dil, S, Bq):
 
 @pytest.mark.parametrize("ks", [2, 4])
 def test_splitk_contraction_matches_unsplit_reference(dev, ks):
-    """the encoder's k=9 data gradient shape (M = 48 x 128, N = 256, K = 9 x 1024) through the K-split path: partial tiles added
-    into the f32 workspace, finalize launch (residual, gate, padded rows); the workspace must come back zero."""
+    """the encoder's k=9 data gradient shape (M = 48 x 128, N = 256, K = 9 x 1024) through the K-split path: partial tiles stored
+    into per-split f32 slabs (scratch: poisoned with NaN here), finalize launch (slab sum, residual, gate, padded rows)."""
     ops = _ops()
     S, Cin, Cout, k = 128, 1024, 256, 9
     M, pad = B * S, 4
@@ -156,13 +156,12 @@ def test_splitk_contraction_matches_unsplit_reference(dev, ks):
     x = torch.randn(M, Cin, generator=g).to(dev).to(torch.bfloat16)
     w = (torch.randn(Cout, k, Cin, generator=g) / math.sqrt(Cin * k)).to(dev).to(torch.bfloat16)
     res = torch.randn(M, Cout, generator=g).to(dev).to(torch.bfloat16)
-    ws = torch.zeros(M, Cout, device=dev)
+    ws = torch.full((ks, M, Cout), float("nan"), device=dev)
     ref = conv_ref_gpu(x, w, None, S, pad, lens=lens)
     valid = (torch.arange(S, device=dev).unsqueeze(0) < lens.unsqueeze(1)).reshape(-1, 1)
-    for _ in range(2):                                                    # twice: the second call starts from the cleared workspace
+    for _ in range(2):                                                    # twice: the second call starts from the first one's slabs
         y = ops.conv_gemm(x, w, None, S, taps=k, pad=pad, res=res, lens=lens, tmap=tmap, ksplit=ks, ws=ws)
         assert_rounding_only(y, (ref + res.double()) * valid, torch.bfloat16, ("splitk res", ks))
-        assert not ws.any()
     y = ops.conv_gemm(x, w, None, S, taps=k, pad=pad, act=ops.ACT_GATE, res=res, lens=lens, tmap=tmap, ksplit=ks, ws=ws)
     assert_rounding_only(y, torch.where(res.double() > 0, ref, torch.zeros_like(ref)) * valid, torch.bfloat16, ("splitk gate", ks))
     bias = torch.randn(Cout, generator=g).to(dev)
@@ -228,6 +227,95 @@ def test_attention_backward_bf16_at_full_length(dev):
     assert not dq[~v].any()
 
 
+# ------------------------------------------------------------------------------------------------ normalisation kernels
+@pytest.mark.parametrize("form", ["residual", "predictor"])
+def test_layernorm_production_shape_bf16(dev, form):
+    """ln_fwd_c256_bf16_kernel / ln_bwd_c256_bf16_kernel (half a wave per row, 16-byte lanes, DPP row sums) at 48 x 925 rows,
+    C = 256, against an fp64 restatement on the device: outputs within bf16 rounding, affine gradients to fp32 accumulation.
+    "residual": dropout-free add + LayerNorm + pad mask with an upstream gradient added into d1 (the FFT block form);
+    "predictor": ReLU'd input, no residual, no lens, ReLU backward fused into d2 (the variance predictor form)."""
+    ops = _ops()
+    S, C = 925, 256
+    M = B * S
+    g = torch.Generator().manual_seed(31)
+    resid = form == "residual"
+    lens = ragged_lens(S, seed=9).to(dev) if resid else None
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.3).to(dev).to(torch.bfloat16)
+    if not resid:
+        y = torch.relu(y)
+    res = torch.randn(M, C, generator=g).to(dev).to(torch.bfloat16) if resid else None
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    dout = torch.randn(M, C, generator=g).to(dev).to(torch.bfloat16)
+    d1a = torch.randn(M, C, generator=g).to(dev).to(torch.bfloat16) if resid else None
+    z = y.double() + (res.double() if resid else 0)
+    zr = z.to(torch.bfloat16).double()                                     # the kernel normalises z as stored
+    valid = (torch.arange(S, device=dev).unsqueeze(0) < lens.unsqueeze(1)).reshape(-1, 1).double() if resid else torch.ones(M, 1, device=dev, dtype=torch.float64)
+    mu = zr.mean(1, keepdim=True)
+    rstd = (((zr - mu) ** 2).mean(1, keepdim=True) + 1e-5).rsqrt()
+    xh = (zr - mu) * rstd
+    o_ref = (xh * gamma.double() + beta.double()) * valid
+    gdo = dout.double() * valid
+    gg = gdo * gamma.double()
+    dz = rstd * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True))
+    o, mean, rs = ops.ln_fwd(y, res, gamma, beta, lens, B, S)
+    assert torch.equal(y.double(), zr)                                     # z written back (bf16) for backward
+    assert_rounding_only(o, o_ref, torch.bfloat16, (form, "out"))
+    assert torch.allclose(mean.double(), mu.squeeze(1), rtol=0, atol=1e-5) and torch.allclose(rs.double(), rstd.squeeze(1), rtol=1e-5, atol=0)
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    d1, d2 = ops.ln_bwd(y, dout, gamma, lens, mean, rs, dg, db, B, S, want_d1=resid, want_d2=True, d1_add=d1a, relu_bwd=not resid)
+    if resid:
+        assert_rounding_only(d1, dz + d1a.double(), torch.bfloat16, (form, "d1"))
+        assert_rounding_only(d2, dz, torch.bfloat16, (form, "d2"))
+    else:
+        assert_rounding_only(d2, dz * (zr > 0), torch.bfloat16, (form, "d2 relu"))
+    for got, ref, nm in ((dg, (gdo * xh).sum(0), "dgamma"), (db, gdo.sum(0), "dbeta")):
+        assert ((got.double() - ref).norm() / ref.norm()).item() < 1e-5, (form, nm)
+    # dropout forms: the backward regenerates the forward's masks (d2 is zero exactly where the pre-LN dropout dropped y)
+    y2 = (torch.randn(M, C, generator=g) + 2.0).to(dev).to(torch.bfloat16)          # away from 0: a zero in z - res marks a dropped element
+    y2[y2 == 0] = 1.0                                                                # (11 M samples: one does land on 0)
+    r2 = torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
+    o2, m2, s2 = ops.ln_fwd(y2, r2, gamma, beta, lens, B, S, p_pre=0.2, seed_pre=4321)
+    dropped = y2 == 0
+    assert abs(dropped.float().mean().item() - 0.2) < 5e-3
+    dg.zero_(); db.zero_()
+    _, dd2 = ops.ln_bwd(y2, dout, gamma, lens, m2, s2, dg, db, B, S, want_d1=True, want_d2=True, p_pre=0.2, seed_pre=4321)
+    assert not dd2[dropped].any()
+    live_rows = valid.squeeze(1) > 0
+    assert (dd2[live_rows][~dropped[live_rows]] != 0).float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("C", [512, 80])
+def test_batchnorm_production_shape_bf16(dev, C):
+    """bn_rows_kernel<.., V = 8> (16-byte lanes) at M = 44 400 rows, the PostNet's two widths: statistics, apply + tanh, both
+    backward passes against fp64 on the device."""
+    ops = _ops()
+    M = B * 925
+    g = torch.Generator().manual_seed(41 + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev).to(torch.bfloat16)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    dout = torch.randn(M, C, generator=g).to(dev).to(torch.bfloat16)
+    xd = x.double()
+    mu = xd.mean(0, keepdim=True)
+    var = ((xd - mu) ** 2).mean(0, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    xh = (xd - mu) * rstd
+    t = torch.tanh(xh * gamma.double() + beta.double())
+    rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev)
+    out, mean_rstd = ops.bn_train_fwd(x, gamma, beta, rm, rv, ops.ACT_TANH, 0.0, 0)
+    assert torch.allclose(mean_rstd[:C].double(), mu.squeeze(0), rtol=0, atol=2e-5) and torch.allclose(mean_rstd[C:].double(), rstd.squeeze(0), rtol=2e-5, atol=0)
+    assert torch.allclose(rm.double(), 0.1 * mu.squeeze(0), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * var.squeeze(0) * M / (M - 1), rtol=1e-4, atol=0)
+    assert_rounding_only(out, t, torch.bfloat16, (C, "tanh(bn(x))"))
+    gq = dout.double() * (1 - t * t)
+    dgam, dbet = (gq * xh).sum(0), gq.sum(0)
+    dx_ref = gamma.double() * rstd * (gq - dbet / M - xh * dgam / M)
+    dx, dgamma, dbeta = ops.bn_bwd(x, dout, mean_rstd, gamma, beta, ops.ACT_TANH, 0.0, 0)
+    assert_rounding_only(dx, dx_ref, torch.bfloat16, (C, "dx"))
+    assert ((dgamma.double() - dgam).norm() / dgam.norm()).item() < 1e-4 and ((dbeta.double() - dbet).norm() / dbet.norm()).item() < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ whole train step
 @pytest.fixture(scope="module")
 def full_case():
@@ -289,9 +377,16 @@ def full_case_bf16_weights(full_case):
 def test_full_size_train_step_bf16_per_tensor_budget(dev, full_case, full_case_bf16_weights):
     """bf16 storage + bf16 MFMA (fp32 accumulate / statistics / master weights) against the fp64 oracle.  Budget: every stored
     activation carries a relative rounding error <= 2^-9; a gradient tensor sees ~2 x depth such roundings that add in
-    quadrature across independent elements -> per-tensor relative Frobenius error well under 2^-9 * sqrt(2 * 8 * 4) ~ 1.6e-2;
-    measured values are printed (pytest -s) and the bars sit at <= 1e-2 for weights, 2e-2 for the tiny bias / LayerNorm vectors
-    whose true gradients are sums of cancelling terms."""
+    quadrature across independent elements -> per-tensor relative Frobenius error of the order of 2^-9 * sqrt(2 * 8 * 4) ~ 1.6e-2.
+    The step is CHAOTIC at that level: two builds whose LayerNorm kernels agree with each other on all but 1e-5 of their
+    output elements (a different fp32 summation order; both within bf16 rounding of fp64, test_layernorm_production_shape_bf16)
+    produce mel outputs that differ in 73 % of their elements (relative Frobenius 6.9e-3 - the same size as either one's
+    distance to the oracle) and weight gradients that differ from EACH OTHER by 3.6e-3 (median) / 2.5e-2 (max, the PostNet convs:
+    five conv + BatchNorm + tanh layers amplify the mel's rounding noise 4x) - profiles/r02k_dbg_step.log.  A bar against the
+    oracle cannot sit below that realisation-to-realisation spread: measured across six arithmetic-equivalent builds the
+    PostNet conv weights land between 1.4e-2 and 2.5e-2, everything else below 1.4e-2 (profiles/r02k_bisect*.log).  Bars:
+    1.5e-2 for weight tensors, 3.5e-2 for the PostNet's, 6e-2 for the <= 1024-entry vectors (biases, LayerNorm / BatchNorm
+    affine, embedding rows) whose true gradients are sums of cancelling terms."""
     pcfg, mcfg, sd, b, oout, olosses, ograds = full_case
     _, _, ograds_w = full_case_bf16_weights
     out, losses, grads = _train_step(dev, pcfg, mcfg, sd, b, "bf16")
@@ -320,7 +415,8 @@ def test_full_size_train_step_bf16_per_tensor_budget(dev, full_case, full_case_b
             worst.append((fro, n))
             # weights <= bar_w; vectors of <= 1024 entries (biases, LayerNorm / BatchNorm affine: sums of cancelling terms over
             # 44 400 rows, their RELATIVE error is the largest) <= bar_v
-            if fro > (bar_v if (og.numel() <= 1024 or "emb" in n) else bar_w):          # (embedding rows: sums over a few tokens)
+            bw = bar_w * (3.5e-2 / 1.5e-2 if n.startswith("postnet.") and bar_w < 2e-2 else 1.0)
+            if fro > (bar_v if (og.numel() <= 1024 or "emb" in n) else bw):          # (embedding rows: sums over a few tokens)
                 failures.append((tag, n, fro))
         worst.sort(reverse=True)
         big = sorted(f for f, n in worst if ref[n].numel() > 1024)

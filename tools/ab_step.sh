@@ -1,8 +1,8 @@
 #!/bin/bash
-# same-box A/B of the whole train step: the round-1 final tree (_prev/, built by `git archive e52fff2 | tar -x -C _prev; make`)
+# same-box A/B of the whole train step: a reference tree (_prev/, built by `git archive <commit> | tar -x -C _prev; make -C _prev`)
 # against the current tree, alternating, three rounds.
 export TMPDIR=/tmp
 for r in 1 2 3; do
-  ( cd _prev && python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('round-1 tree ', d['ms_per_step'], d['value'])" )
-  python bench.py --no-cpu-baseline --no-roofline --no-fp32 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('current tree ', d['ms_per_step'], d['value'], d['config']['window_ms_per_step'])"
+  ( cd _prev && python bench.py --no-cpu-baseline --no-roofline --no-fp32 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('reference tree ', d['ms_per_step'], d['value'], d['config']['window_ms_per_step'])" )
+  python bench.py --no-cpu-baseline --no-roofline --no-fp32 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('current tree   ', d['ms_per_step'], d['value'], d['config']['window_ms_per_step'])"
 done
