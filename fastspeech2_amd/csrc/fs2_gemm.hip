@@ -934,7 +934,8 @@ static void launch_skinny(const ConvGemmArgs& a, hipStream_t stream) {
 
 // defined in fs2_gemm_p.hip
 bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks);
-void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl, int ks, float* ws);
+void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl, int ks, float* ws,
+                            float* tail_ws);
 
 // Which kernel a launch description dispatches to: a PURE function of the description (no state, no environment in the
 // shipped build), shared by fs2_conv_gemm and by the query entry point fs2_conv_gemm_variant that bench.py uses to attribute
@@ -994,10 +995,10 @@ extern "C" int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens,
     return conv_gemm_pick(a, dtype, has_map != 0).variant;
 }
 
-extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
-                             long ldy, const int32_t* lens, const int32_t* tile_map, int M, int N, int Cin, int S, int taps, int dil,
-                             int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
-                             hipStream_t stream) {
+static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
+                          long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin, int S, int taps,
+                          int dil, int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale,
+                          int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(X && W && Y, "conv_gemm: null pointer");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0 && dil > 0, "conv_gemm: bad shape M=%d N=%d Cin=%d S=%d taps=%d", M, N, Cin, S, taps);
     FS2_CHECK_ARG(M % S == 0, "conv_gemm: M=%d not a multiple of S=%d", M, S);
@@ -1019,7 +1020,7 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
         else launch_skinny<128>(a, stream);
     } else if (pk.variant == FS2_GEMM_PERSIST || pk.variant == FS2_GEMM_PERSIST_1TAP) {
         static const int abl = fs2_dev_env("FS2_GEMM_ABL", 0);
-        fs2_conv_gemm_p_launch(a, tile_map, stream, abl, 1, nullptr);
+        fs2_conv_gemm_p_launch(a, tile_map, stream, abl, 1, nullptr, tail_ws);
     } else if (pk.variant == FS2_GEMM_RING) {
         static Fs2DevOnce ring_once;
         const int dyn1 = RingCfg<true>::B_OFF + RingCfg<true>::D * RING_B_BYTES;
@@ -1052,6 +1053,28 @@ extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float
     return FS2_OK;
 }
 
+extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
+                             long ldy, const int32_t* lens, const int32_t* tile_map, int M, int N, int Cin, int S, int taps, int dil,
+                             int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,
+                             hipStream_t stream) {
+    return conv_gemm_impl(X, ldx, W, bias, R, ldr, Y, ldy, lens, tile_map, nullptr, M, N, Cin, S, taps, dil, pad, act, slope, in_act,
+                          in_slope, accumulate, out_scale, dtype, stream);
+}
+
+// fs2_conv_gemm with a scratch workspace for the persistent kernel's tail split (fs2_gemm_p.hip, PSched::tws): when the output
+// tiles do not fill a whole number of rounds over the CUs, the last partial round is K-split so that it costs a fraction of a
+// round.  tail_ws: fs2_conv_gemm_tail_ws_bytes() bytes of f32 scratch (any contents; must not be shared by launches that can
+// run concurrently).  Launches the persistent kernel does not take ignore it.  Same results as fs2_conv_gemm up to the fp32
+// summation order of the split tiles.
+extern "C" int fs2_conv_gemm_tail(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
+                                  long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin,
+                                  int S, int taps, int dil, int pad, int act, float slope, int in_act, float in_slope,
+                                  int accumulate, float out_scale, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(!tail_ws || ((uintptr_t)tail_ws & 15) == 0, "conv_gemm_tail: tail_ws must be 16-byte aligned");
+    return conv_gemm_impl(X, ldx, W, bias, R, ldr, Y, ldy, lens, tile_map, tail_ws, M, N, Cin, S, taps, dil, pad, act, slope, in_act,
+                          in_slope, accumulate, out_scale, dtype, stream);
+}
+
 // K-split form of fs2_conv_gemm for contractions with few output tiles and a long reduction (the encoder's k=9 data gradient:
 // 48 tiles x 144 K-steps on 256 CUs): `ksplit` workgroups share one output tile, each reduces a contiguous range of Cin
 // chunks and stores its partial tile into its own slab of `ws` (f32 scratch, ksplit x M x N, any contents); one more launch
@@ -1067,7 +1090,7 @@ extern "C" int fs2_conv_gemm_splitk(const void* X, long ldx, const void* W, cons
     ConvGemmArgs a;
     conv_gemm_fill(a, X, ldx, W, bias, R, ldr, Y, ldy, lens, M, N, Cin, S, taps, dil, pad, act, slope, FS2_ACT_NONE, 0.f, 0, out_scale, dtype);
     FS2_CHECK_ARG(fs2_conv_gemm_p_ok(a, tile_map != nullptr, dtype, ksplit), "conv_gemm_splitk: shape not supported (M=%d N=%d Cin=%d taps=%d ksplit=%d)", M, N, Cin, taps, ksplit);
-    fs2_conv_gemm_p_launch(a, tile_map, stream, 0, ksplit, ws);
+    fs2_conv_gemm_p_launch(a, tile_map, stream, 0, ksplit, ws, nullptr);
     FS2_CHECK_LAUNCH("conv_gemm_splitk");
     return FS2_OK;
 }

@@ -55,6 +55,12 @@ template <> struct PCfg<true, false> {
     static constexpr int D = 3, HALO = 0, A_BYTES = 256 * 128, SCRATCH = 0, B_OFF = 3 * 256 * 128, NJA = 8;
     static constexpr int AUX = B_OFF + D * 16384;
 };
+// a pointer the code knows to be wave-uniform, pinned into SGPRs (the LDS-DMA's base operand must be scalar)
+__device__ __forceinline__ const unsigned char* p_uniform(const unsigned char* q) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+}
 template <int N> __device__ __forceinline__ void p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 static constexpr int P_MAXB = 1024;                       // lens[] staged in LDS
 static constexpr int P_AUX_BYTES = P_MAXB * 4 + 4 * 512;  // lens + one 128-float bias line per consumer wave
@@ -70,60 +76,119 @@ struct PSched {
                                // splitk_finalize_kernel sums the slabs into the bf16 output - for few-tile, long-reduction shapes
                                // (the encoder's k=9 data gradient: 48 tiles x 144 K-steps on 256 CUs)
     float* ws;
+    float* tws;                // tail slabs (one 256x128 f32 tile per workgroup) or null.  Non-null (and ks == 1): the LAST, partial
+    int tks_max;               // round of output tiles is K-split tks (<= tks_max, a power of two) ways so that it takes 1/tks of a
+                               // round instead of a whole one: 300 real tiles on 256 CUs ran as 2 rounds of 144 K-steps (the
+                               // k=9 data gradient), now 1 round + 44 tiles x 4 parts of 36 steps.  The parts store f32 partial
+                               // tiles into their workgroup's slab, p_tail_finalize_kernel sums them and applies the epilogue.
     int order;                 // 0: M-fastest over all workgroups (neighbours share the weight slice);
                                // 1: per XCD, N-fastest: the G/8 workgroups the dispatcher places on one XCD (b % 8) walk ALL
                                //    N-tiles of the same M-tile together, so the activation tile is fetched into that XCD's L2
                                //    once instead of once per N-tile (QKV re-read its input 6x from the Infinity Cache)
 };
 
-// index (into the real-M-tile list), N-tile and K-split of the k-th unit of workgroup s.b; false when it has no k-th unit
-__device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt, int& sp) {
+// Schedule of one workgroup GROUP (order 0: all G workgroups and all tiles; order 1: the G/8 workgroups of one XCD and the
+// tiles of the M-tiles mi = x mod 8): R full rounds, then `tail` tiles left over, each split `tks` ways (1 = not split).
+struct PPlan { int Gg, j, x, T, R, tail, tks; };
+__device__ __forceinline__ PPlan p_plan(const PSched& s, int b) {
+    PPlan p;
+    if (s.order == 0) { p.Gg = s.G; p.j = b; p.x = 0; p.T = s.n_real * s.ntn * s.ks; }
+    else {
+        p.x = b & 7; p.j = b >> 3; p.Gg = s.G >> 3;
+        const int nx = s.n_real > p.x ? (s.n_real - p.x + 7) >> 3 : 0;
+        p.T = nx * s.ntn * s.ks;
+    }
+    p.R = p.T / p.Gg;
+    p.tail = p.T - p.R * p.Gg;
+    p.tks = 1;
+    if (s.tws && p.tail > 0) {
+        int t = 1;
+        while (2 * t <= s.tks_max && 2 * t * p.tail <= p.Gg) t *= 2;
+        p.tks = t;
+    }
+    return p;
+}
+// position in the group's unit list -> (index into the real-M-tile list, N-tile, uniform K-split index)
+__device__ __forceinline__ void p_pos(const PSched& s, const PPlan& p, int pos, int& mi, int& nt, int& sp) {
     if (s.order == 0) {
-        const int u = s.b + k * s.G;
-        if (u >= s.n_real * s.ntn * s.ks) return false;
-        const int rest = u / s.ks;
-        sp = u - rest * s.ks;
+        const int rest = pos / s.ks;
+        sp = pos - rest * s.ks;
         nt = rest / s.n_real;
         mi = rest - nt * s.n_real;
-        return true;
+    } else {
+        const int per = s.ntn * s.ks;
+        const int mil = pos / per, r = pos - mil * per;
+        nt = r / s.ks;
+        sp = r - nt * s.ks;
+        mi = p.x + 8 * mil;
     }
-    const int x = s.b & 7, j = s.b >> 3, pos = k * (s.G >> 3) + j, per = s.ntn * s.ks;
-    const int mil = pos / per, r = pos - mil * per;
-    nt = r / s.ks;
-    sp = r - nt * s.ks;
-    mi = x + 8 * mil;
-    return mi < s.n_real;
+}
+// k-th unit of workgroup s.b: index into the real-M-tile list, N-tile, first Cin chunk and chunk count, tail part count (1 =
+// a whole tile); false when the workgroup has no k-th unit
+__device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt, int& kc0, int& nkc, int& np) {
+    const PPlan p = p_plan(s, s.b);
+    int pos, part = 0;
+    np = 1;
+    if (k < p.R) pos = k * p.Gg + p.j;
+    else if (k == p.R && p.j < p.tail * p.tks) { pos = p.R * p.Gg + p.j / p.tks; part = p.j % p.tks; np = p.tks; }
+    else return false;
+    int sp;
+    p_pos(s, p, pos, mi, nt, sp);
+    nkc = s.nkc_u / np;
+    kc0 = sp * s.nkc_u + part * nkc;
+    return true;
 }
 __device__ __forceinline__ int p_ntiles(const PSched& s) {
-    if (s.order == 0) return (s.n_real * s.ntn * s.ks - s.b + s.G - 1) / s.G;
-    const int x = s.b & 7, j = s.b >> 3, g8 = s.G >> 3;
-    const int nx = s.n_real > x ? (s.n_real - x + 7) >> 3 : 0;
-    return (nx * s.ntn * s.ks - j + g8 - 1) / g8;
+    const PPlan p = p_plan(s, s.b);
+    return p.R + (p.j < p.tail * p.tks ? 1 : 0);
+}
+// chunk count of the workgroup's LAST unit (the only one that can be a tail part)
+__device__ __forceinline__ int p_last_nkc(const PSched& s) {
+    const PPlan p = p_plan(s, s.b);
+    return (p.j < p.tail * p.tks) ? s.nkc_u / p.tks : s.nkc_u;
 }
 
-// k-th unit of this workgroup -> (M-tile, N-tile, first Cin chunk); the M-tile ids of a workgroup's first 64 units sit in
-// `mt_list` (lane k)
-__device__ __forceinline__ void p_tile_of(const PSched& s, int k, unsigned mt_list, int& mt, int& nt, int& kc0, int* split = nullptr) {
-    int mi, sp;
-    (void)p_unit(s, k, mi, nt, sp);
-    if (split) *split = __builtin_amdgcn_readfirstlane(sp);
-    kc0 = __builtin_amdgcn_readfirstlane(sp * s.nkc_u);      // wave-uniform by construction; tell the compiler (SGPR operand of the DMA)
-    mt = s.tmap ? (int)__builtin_amdgcn_readlane(mt_list, k) : mi;
+// A wave's view of its workgroup's unit list: lane i holds unit 64 * blk + i, packed - v0 = M-tile | N-tile << 20 | parts << 28,
+// v1 = first Cin chunk | chunk count << 16 - so that the schedule arithmetic (divisions, the tile-map lookup) runs once per 64
+// units, outside the K loops, and a unit costs two v_readlane.  (The first tail-split build recomputed p_unit per tile in three
+// places: 35 more spilled SGPRs in the main loop; so did a reload path for workgroups with more than 64 units - the launcher
+// sends such launches, > 16 384 output tiles, to the ring kernel instead.)
+struct PUnits { unsigned v0, v1; };
+__device__ __forceinline__ void p_units_load(const PSched& s, int lane, PUnits& t) {
+    int mi, nt, kc0, nkc, np;
+    unsigned a0 = 0, a1 = 0;
+    if (p_unit(s, lane, mi, nt, kc0, nkc, np)) {
+        const int mt = s.tmap ? s.tmap[1 + mi] : mi;
+        a0 = (unsigned)mt | ((unsigned)nt << 20) | ((unsigned)np << 28);
+        a1 = (unsigned)kc0 | ((unsigned)nkc << 16);
+    }
+    t.v0 = a0; t.v1 = a1;
+}
+// k-th unit of this workgroup -> (M-tile, N-tile, first Cin chunk, tail part count, uniform K-split index)
+__device__ __forceinline__ void p_tile_of(const PSched& s, int k, const PUnits& t, int& mt, int& nt, int& kc0, int* split = nullptr,
+                                          int* nparts = nullptr) {
+    const unsigned a0 = __builtin_amdgcn_readlane(t.v0, k), a1 = __builtin_amdgcn_readlane(t.v1, k);
+    mt = (int)(a0 & 0xfffffu);
+    nt = (int)((a0 >> 20) & 0xffu);
+    kc0 = __builtin_amdgcn_readfirstlane((int)(a1 & 0xffffu));          // (uniform already: keeps the DMA base an SGPR operand)
+    if (nparts) *nparts = (int)(a0 >> 28);
+    if (split) *split = kc0 / s.nkc_u;
 }
 
 // ------------------------------------------------------------------------------------------------ loader waves
 template <bool ONE_TAP, bool WIDE>
 __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int lw,
-                                         unsigned mt_list, int ntiles) {
+                                         const PUnits& units, int ntiles) {
     typedef PCfg<ONE_TAP, WIDE> C;
     constexpr int D = C::D, NJA = C::NJA;
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(a.X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(a.W);
     const int nkc = sc.nkc_u;                                // Cin chunks per unit (a K-split owns a contiguous range of chunks)
+    const int nkc_last = p_last_nkc(sc);                     // ... of the workgroup's last unit (a tail part has fewer)
     const int taps = ONE_TAP ? 1 : a.taps;
     const int nsteps = taps * nkc;
-    const int total = ntiles * nsteps;                       // K-steps of this workgroup, all units
-    const int nchunks = ntiles * nkc;
+    const int total = (ntiles - 1) * nsteps + taps * nkc_last;   // K-steps of this workgroup, all units
+    const int nchunks = (ntiles - 1) * nkc + nkc_last;
     int kc0A = 0, kc0B = 0;                                  // first chunk of the unit the A / B offsets are set for
     const int lr = lane >> 3, lc = lane & 7;
     const int arows = 256 + (taps - 1) * a.dil;
@@ -132,7 +197,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     unsigned offA[NJA], ldsA[NJA], offB[4];
     auto set_A = [&](int k) {
         int mt, nt;
-        p_tile_of(sc, k, mt_list, mt, nt, kc0A);
+        p_tile_of(sc, k, units, mt, nt, kc0A);
         const int m0 = mt * 256;
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
@@ -146,7 +211,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     };
     auto set_B = [&](int k) {
         int mt, nt;
-        p_tile_of(sc, k, mt_list, mt, nt, kc0B);
+        p_tile_of(sc, k, units, mt, nt, kc0B);
         const int n0 = nt * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -160,7 +225,7 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     int kA = -1, kB = -1;                                    // tiles the per-lane offsets are set for
     auto issue_A = [&](int k, int kc, int buf_or_slot) {
         if (k != kA) { set_A(k); kA = k; }
-        const unsigned char* base = Xb + (size_t)(kc0A + kc) * 128;
+        const unsigned char* base = p_uniform(Xb + (size_t)(kc0A + kc) * 128);
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
             const unsigned d = (ldsA[j] == 0xffffffffu) ? smem_base + C::SCRATCH : smem_base + buf_or_slot * C::A_BYTES + ldsA[j];
@@ -170,14 +235,14 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
     auto issue_step = [&]() {                                // operands of global step `is` -> slot `islot`
         if (ik != kB) { set_B(ik); kB = ik; }
         if (ONE_TAP) issue_A(ik, ikc, islot);
-        const unsigned char* base = Wb + ((size_t)itap * a.Cin + (size_t)(kc0B + ikc) * 64) * 2;
+        const unsigned char* base = p_uniform(Wb + ((size_t)itap * a.Cin + (size_t)(kc0B + ikc) * 64) * 2);
         const unsigned d0 = smem_base + C::B_OFF + islot * P_B_BYTES + lw * 4096;
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16_sbase(offB[j], base, d0 + j * 1024);
     };
     auto advance_issue = [&]() {
         ++is;
-        if (++itap == taps) { itap = 0; if (++ikc == nkc) { ikc = 0; ++ik; } }
+        if (++itap == taps) { itap = 0; if (++ikc == (ik == ntiles - 1 ? nkc_last : nkc)) { ikc = 0; ++ik; } }
         if (++islot == D) islot = 0;
     };
     if (!ONE_TAP) issue_A(0, 0, 0);
@@ -202,12 +267,12 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
         __builtin_amdgcn_s_barrier();                        // publishes slot(cs); the consumers have left slot(cs-1)
         if (!ONE_TAP && ctap == 0 && gc + 1 < nchunks) {
             int nk = ck, nkc_ = ckc + 1;
-            if (nkc_ == nkc) { nkc_ = 0; ++nk; }
+            if (nkc_ == (ck == ntiles - 1 ? nkc_last : nkc)) { nkc_ = 0; ++nk; }
             issue_A(nk, nkc_, (gc + 1) & 1);
         }
         if (is < total) issue_step();
         advance_issue();
-        if (++ctap == taps) { ctap = 0; ++gc; if (++ckc == nkc) { ckc = 0; ++ck; } }
+        if (++ctap == taps) { ctap = 0; ++gc; if (++ckc == (ck == ntiles - 1 ? nkc_last : nkc)) { ckc = 0; ++ck; } }
     }
 }
 
@@ -371,6 +436,80 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, co
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = o;
 }
 
+// tail part: the partial 256x128 tile goes to the workgroup's slab, tile-local row-major (row = wm*64 + mb*32 + fl)
+__device__ __forceinline__ void p_epilogue_part(float* slab, f32x16 (&acc)[2][4], int wm, int fl, int fh) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float* wrow = slab + (size_t)(wm * 64 + mb * 32 + fl) * 128;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            float c[2][8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][e]), __float_as_uint(acc[mb][nb][4 + e]), false, false);
+                u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][8 + e]), __float_as_uint(acc[mb][nb][12 + e]), false, false);
+                c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
+                c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int n = nb * 32 + ch * 16 + fh * 8;
+                *reinterpret_cast<float4*>(wrow + n) = make_float4(c[ch][0], c[ch][1], c[ch][2], c[ch][3]);
+                *reinterpret_cast<float4*>(wrow + n + 4) = make_float4(c[ch][4], c[ch][5], c[ch][6], c[ch][7]);
+            }
+        }
+    }
+}
+
+// Tail tiles -> Y.  Grid (16, G): block (sub, b) looks at workgroup b of the contraction launch; when b ran part 0 of a split
+// tail tile it sums that tile's tks slabs (workgroups b .. of the same group) and applies bias / activation / residual / gate /
+// scale / padded-row zero - one thread per 8 consecutive columns of one row, 16 blocks per tile.  Every other block exits.
+template <int ACT>
+__global__ void __launch_bounds__(256) p_tail_finalize_kernel(ConvGemmArgs a, PSched sc) {
+    sc.b = blockIdx.y;
+    if (sc.tmap) { sc.n_real = sc.tmap[0]; sc.n_pad = sc.ntm - sc.n_real; }
+    const PPlan p = p_plan(sc, sc.b);
+    if (p.tks <= 1 || p.j >= p.tail * p.tks || (p.j % p.tks) != 0) return;
+    int mi, nt, sp;
+    p_pos(sc, p, p.R * p.Gg + p.j / p.tks, mi, nt, sp);
+    const int mt = sc.tmap ? sc.tmap[1 + mi] : mi;
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // 0 .. 4095: (row, 8-column chunk) of the tile
+    const int r = idx >> 4, cn = (idx & 15) * 8;
+    const int m = mt * 256 + r, n = nt * 128 + cn;
+    if (m >= a.M || n >= a.N) return;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < p.tks; ++q) {
+        const int wg = sc.order == 0 ? sc.b + q : p.x + 8 * (p.j + q);
+        const float* sl = sc.tws + (size_t)wg * (256 * 128) + r * 128 + cn;
+        const float4 x0 = *reinterpret_cast<const float4*>(sl), x1 = *reinterpret_cast<const float4*>(sl + 4);
+        v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a.bias[n + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(v[e], a.slope);
+    const bool gate = a.act == FS2_ACT_GATE;
+    if (a.R) {
+        const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.R) + (size_t)m * a.ldr + n);
+        const uint32_t* u = reinterpret_cast<const uint32_t*>(&rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+            v[2 * e] = gate ? (r0 > 0.f ? v[2 * e] : 0.f) : v[2 * e] + r0;
+            v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
+        }
+    }
+    bool padrow = false;
+    if (a.lens) { const int b = m / a.S; padrow = (m - b * a.S) >= a.lens[b]; }
+    uint4 o;
+    uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ou[e] = padrow ? 0u : pack_bf16x2(v[2 * e] * a.out_scale, v[2 * e + 1] * a.out_scale);
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = o;
+}
+
 // leaky-ReLU on a landed activation fragment (HiFi-GAN's pre-activation convolutions; the LDS-DMA path cannot transform data on
 // its way in): widen both halves of each dword, max(x, slope x) (0 < slope < 1), hardware bf16 pack - 7 VALU per dword, two
 // fragments per k-slice of eight MFMAs
@@ -386,13 +525,14 @@ __device__ __forceinline__ u32x4 p_lrelu(u32x4 v, float slope) {
 // ABL bit 16 (shipped): leaky-ReLU prologue on the activation fragments.  Other ABL bits (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue
 template <bool ONE_TAP, bool WIDE, int ABL>
 __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int wm,
-                                           unsigned mt_list, int ntiles, const int32_t* lens_s, float* bias_s) {
+                                           const PUnits& units, int ntiles, const int32_t* lens_s, float* bias_s) {
     typedef PCfg<ONE_TAP, WIDE> C;
     constexpr int D = C::D;
     const int nkc = sc.nkc_u;
+    const int nkc_last = p_last_nkc(sc);
     const int taps = ONE_TAP ? 1 : a.taps;
     const int nsteps = taps * nkc;
-    const int total = ntiles * nsteps;
+    const int total = (ntiles - 1) * nsteps + taps * nkc_last;
     const int fl = lane & 31, fh = lane >> 5;
     const unsigned smem_u = lds_addr(smem);
     // fragment addresses.  Lane (fl, fh) reads 16-byte chunk c = fh*4 + j of its row in k-slice j; chunks are XOR-swizzled
@@ -460,8 +600,9 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
     }
     for (int k = 0; k < ntiles; ++k) {
         int mt, nt, kc0_unused;
-        int split;
-        p_tile_of(sc, k, mt_list, mt, nt, kc0_unused, &split);
+        int split, nparts;
+        p_tile_of(sc, k, units, mt, nt, kc0_unused, &split, &nparts);
+        const int nkc_k = (k == ntiles - 1) ? nkc_last : nkc;
         const int m0 = mt * 256, n0 = nt * 128;
         // tap-validity bits of this lane's two rows (bit j: tap j stays inside the row's own sequence)
         unsigned vmask[2] = {0xffffffffu, 0xffffffffu};
@@ -493,7 +634,7 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
 
         auto run_tile = [&](auto maskc) {
             constexpr bool MASKED = decltype(maskc)::value;
-            for (int kc = 0; kc < nkc; ++kc) {
+            for (int kc = 0; kc < nkc_k; ++kc) {
                 for (int tap = 0; tap < taps; ++tap) {
                     const int abuf = ONE_TAP ? slot : (gc & 1);
                     const bool live0 = (vmask[0] >> tap) & 1u, live1 = (vmask[1] >> tap) & 1u;
@@ -525,7 +666,9 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         // them first, AS OUTPUTS of the wait, so every copy is ordered behind it (one LDS drain per tile, not per step).
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
 
-        if (sc.ks > 1) {
+        if (nparts > 1) {
+            p_epilogue_part(sc.tws + (size_t)sc.b * (256 * 128), acc, wm, fl, fh);
+        } else if (sc.ks > 1) {
             p_epilogue_splitk(a, sc.ws + (size_t)split * a.M * a.N, acc, m0, n0, wm, fl, fh);
         } else if (!(ABL & 4)) {
             FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wm, fl, fh, lens_s, bias_s, lane)));
@@ -558,16 +701,9 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
     int32_t* lens_s = reinterpret_cast<int32_t*>(smem + C::AUX);
     float* bias_s = reinterpret_cast<float*>(smem + C::AUX + P_MAXB * 4) + (wave & 3) * 128;
     const int ntiles = p_ntiles(sc);                         // 0 when every real tile went to other workgroups
-    // M-tile ids of this workgroup's tiles (<= 64 per workgroup: guaranteed by the launcher when a tile map is used);
-    // loaded separately in the two roles so that the consumers' register pressure cannot spill the loaders' copy
-    auto load_mt_list = [&]() -> unsigned {
-        unsigned v = 0;
-        if (sc.tmap) {
-            int mi, nt, sp;
-            if (p_unit(sc, lane, mi, nt, sp)) v = (unsigned)sc.tmap[1 + mi];
-        }
-        return v;
-    };
+    // this workgroup's units (loaded separately in the two roles: a wave keeps its own packed copy in two VGPRs)
+    PUnits units;
+    p_units_load(sc, lane, units);
     if (wave < 4) {
         // per-sequence lengths -> LDS (the epilogue's padded-row test must not wait on global memory behind its own stores)
         if (a.lens) {
@@ -590,9 +726,9 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
         // the four consumer waves make the staged lengths visible to each other before anyone's epilogue: they all pass
         // the per-step barriers (>= 1) before the first epilogue, and LDS writes are ordered ahead of the wave's barrier
         // arrival by the s_waitcnt lgkmcnt(0) in front of the first barrier.
-        if (ntiles > 0) p_consumer<ONE_TAP, WIDE, ABL>(a, sc, smem, lane, wave, load_mt_list(), ntiles, lens_s, bias_s);
+        if (ntiles > 0) p_consumer<ONE_TAP, WIDE, ABL>(a, sc, smem, lane, wave, units, ntiles, lens_s, bias_s);
     } else if (ntiles > 0) {                                 // (a workgroup without real tiles runs no barrier on either side)
-        p_loader<ONE_TAP, WIDE>(a, sc, smem, lane, wave - 4, load_mt_list(), ntiles);
+        p_loader<ONE_TAP, WIDE>(a, sc, smem, lane, wave - 4, units, ntiles);
     }
 }
 
@@ -712,6 +848,9 @@ static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream
     conv_gemm_p_kernel<ONE_TAP, WIDE, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
 }
 
+// bytes of tail-split scratch fs2_conv_gemm_tail wants: one 256x128 f32 slab per workgroup of a full-chip launch
+extern "C" int fs2_conv_gemm_tail_ws_bytes(void) { return fs2_cu_count() * 256 * 128 * (int)sizeof(float); }
+
 // Eligibility of the persistent kernel (pure function of the launch description; shared with fs2_conv_gemm_variant).
 bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks) {
     const bool inact = a.in_act == FS2_ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f;
@@ -729,21 +868,37 @@ bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks) 
     const bool long_conv = taps >= 3 && (long)taps * (a.Cin >> 6) >= 96 && tiles >= cus / 8;
     if (tiles < (ks > 1 ? cus / 4 : cus / 2) && !long_conv) return false;
     const long G = tiles < cus ? tiles : cus;
-    if (a.lens && (tiles + G - 1) / G > 64) return false;    // a workgroup's M-tile ids travel in one VGPR (lane k = k-th tile)
+    if ((tiles + G - 1) / G > 64) return false;              // a workgroup's units travel in two VGPRs (lane k = k-th unit)
     return true;
 }
 
 // The real-tile count lives in tile_map[0] on the device; the launch geometry must not depend on it (no host sync), so
 // G = min(CUs, all tiles) and workgroups that find no real tile only zero-fill their share of the padded ones.
-void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl, int ks, float* ws) {
+void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl, int ks, float* ws,
+                            float* tail_ws) {
     const int ntm = fs2_cdiv(a.M, 256), ntn = fs2_cdiv(a.N, 128);
     const int cus = fs2_cu_count();
     PSched sc;
     sc.ks = ks; sc.nkc_u = (a.Cin >> 6) / ks; sc.ws = ws;
+    // tail split: parts of >= 8 K-steps, at most 8 per tile, a power of two that divides the Cin chunks.  Only launches of at
+    // most two rounds of tiles (by the static count) with a long reduction (>= 64 K-steps): r02n same-box A/B - the k=9 data
+    // gradient (1.2 rounds x 144 steps) 221 -> 193 us, the encoder's (48 tiles) 93.5 -> 44.9 us; launches of 3+ rounds LOSE
+    // (k=9 forward, 5.4 rounds: 210 -> 220 us; PostNet k=5 109 -> 113.5): the few workgroups of their last round already run
+    // well above the loaded per-tile rate, and the finalize launch costs more than the split saves; short reductions lose too
+    // (k=1 FFN forward, 16 steps: 42.7 -> 50.1 us).
+    sc.tws = nullptr; sc.tks_max = 1;
+    if (tail_ws && ks == 1 && !a.accumulate && (long)ntm * ntn <= 2L * cus && (long)a.taps * sc.nkc_u >= 64) {
+        int t = 1;
+        while (t < 8 && sc.nkc_u % (2 * t) == 0 && a.taps * (sc.nkc_u / (2 * t)) >= 8) t *= 2;
+        static const int tks_env = fs2_dev_env("FS2_P_TKS", 8);          // dev A/B: 1 = tail split off
+        if (t > tks_env) t = tks_env;
+        if (t >= 2) { sc.tws = tail_ws; sc.tks_max = t; }
+    }
     sc.tmap = a.lens ? tile_map : nullptr;
     sc.ntm = ntm; sc.ntn = ntn; sc.b = 0;
     sc.n_real = ntm; sc.n_pad = 0;
     sc.G = (int)((long)ntm * ntn * ks < cus ? (long)ntm * ntn * ks : cus);
+    if (sc.tws) sc.G = cus;                                  // a launch with fewer tiles than CUs is all tail
     static const int g_env = fs2_dev_env("FS2_P_G", 0);
     if (g_env > 0 && g_env < sc.G) sc.G = g_env;
     const int taps = a.taps;
@@ -775,4 +930,5 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
         const long chunks = (long)a.M * (a.N >> 3);
         FS2_ACT_DISPATCH(a.act, (splitk_finalize_kernel<ACT><<<(unsigned)((chunks + 255) / 256), 256, 0, stream>>>(a, ws, ks)));
     }
+    if (sc.tws) FS2_ACT_DISPATCH(a.act, (p_tail_finalize_kernel<ACT><<<dim3(16, (unsigned)sc.G), 256, 0, stream>>>(a, sc)));
 }

@@ -683,7 +683,10 @@ __global__ void bn_stats_fix_kernel(const T* __restrict__ x, float* __restrict__
     stats[C + c] = fmaxf(s2 - s1 * s1 / (float)M, 0.f);
 }
 
-static int bn_vec(const BnArgs& a, int C, int dtype) {     // channels per thread: 8 when every bf16 row chunk is 16-byte addressable
+// channels per thread of the STREAMING modes (1, 3): 8 when every bf16 row chunk is 16-byte addressable.  The reducing modes
+// (0, 2: 1024-thread workgroups, 4 rows in flight per thread) stay at 4: at 8 the 128-register budget of a 1024-thread
+// workgroup spills (r02m: statistics 19.9 -> 29.7 us, backward sums 53.8 -> 82.7 us; apply 28.9 -> 27.8, dx 34.4 -> 33.5).
+static int bn_vec(const BnArgs& a, int C, int dtype) {
     const uintptr_t al = (uintptr_t)a.x | (uintptr_t)a.dout | (uintptr_t)a.res | (uintptr_t)a.out;
     static const int vec_env = fs2_dev_env("FS2_BN_VEC", 8);       // dev A/B only
     if (vec_env == 4) return 4;
@@ -716,7 +719,7 @@ extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
     a.x = x; a.sums = stats;
-    const int vec = bn_vec(a, C, dtype);
+    const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
     int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec);
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
@@ -772,7 +775,7 @@ extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, float* running
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_train_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
     a.x = x; a.sums = stats_ws;
-    const int vec = bn_vec(a, C, dtype);
+    const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
     int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec);
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
@@ -818,9 +821,10 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     BnArgs a = {};
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
-    const int vec = bn_vec(a, C, dtype);
+    int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
     int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec);
     BN_LAUNCH(2, 1024, grid);
+    vec = bn_vec(a, C, dtype);
     grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(3, 256, grid);
     FS2_CHECK_LAUNCH("bn_bwd");
@@ -838,10 +842,11 @@ extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean
     BnArgs a = {};
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
-    const int vec = bn_vec(a, C, dtype);
+    int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
     int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec);
     BN_LAUNCH(2, 1024, grid);
     a.acc_dbeta = dbeta_acc; a.acc_dgamma = dgamma_acc; a.clear = sums_next;
+    vec = bn_vec(a, C, dtype);
     grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(3, 256, grid);
     FS2_CHECK_LAUNCH("bn_bwd_acc");

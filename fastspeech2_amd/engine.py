@@ -68,7 +68,7 @@ class Engine:
         self._pack_pending = False
         self._tmaps = {}
         self._bn_ws = {}
-        self._splitk_ws = {}
+        self._tail_ws = None
 
     # ------------------------------------------------------------------ dropout stream
     _SEED_INC = 0x632BE59BD9B4E019 & 0x7FFFFFFFFFFFFFFF
@@ -243,20 +243,22 @@ class Engine:
 
     def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
         wf, _, b, shape = W[key]
-        return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res, tmap=self._tmap(lens))
+        return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res, tmap=self._tmap(lens),
+                             tail_ws=self._tail_workspace(x.device))
 
     def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None, lens=None):
         """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
         _, wd, _, shape = W[key]
-        M, N, Cin = dy.shape[0], wd.shape[0], wd.shape[-1]
-        ks = ops.splitk_for(M, N, Cin, taps, dy.dtype) if (lens is None or self._tmap(lens) is not None) else 1
-        ws = None
-        if ks > 1:                                  # persistent f32 scratch: one M x N slab per split
-            ws = self._splitk_ws.get((ks, M, N))
-            if ws is None:
-                ws = self._splitk_ws[(ks, M, N)] = torch.empty(ks, M, N, device=dy.device, dtype=torch.float32)
+        # (few-tile, long-reduction shapes - the encoder's k=9 data gradient, 48 tiles x 144 K-steps - are split by the same
+        # tail mechanism: a launch with fewer tiles than CUs is all tail)
         return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens, tmap=self._tmap(lens),
-                             ksplit=ks, ws=ws)
+                             tail_ws=self._tail_workspace(dy.device))
+
+    def _tail_workspace(self, device):
+        """scratch of the persistent kernel's tail split (one per engine: its contractions run on one stream, in order)."""
+        if self._tail_ws is None and device.type == "cuda":
+            self._tail_ws = ops.tail_workspace(device)
+        return self._tail_ws
 
     def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0, lens=None):
         """weight (+ bias) gradient of one contraction.  Weight gradients are OFF the critical path of backward (nothing

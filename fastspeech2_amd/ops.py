@@ -91,9 +91,10 @@ def pack_weight(w, dtype, want_fwd=True, want_dgrad=True, wf=None, wd=None):
 # ------------------------------------------------------------------ contraction
 def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0, lens=None, res=None, out=None,
               in_act=ACT_NONE, in_slope=0.0, accumulate=False, out_scale=1.0, ldx=None, M=None, Cin=None, N=None,
-              ldy=None, tmap=None, ksplit=1, ws=None):
+              ldy=None, tmap=None, ksplit=1, ws=None, tail_ws=None):
     """x: [M, Cin] rows (or any buffer with row stride ldx); wpacked: [N, taps, Cin]; returns [M, N].
-    tmap: tile_map(lens, B, S) of the same lens (optional; lets the persistent kernel skip fully padded M-tiles)."""
+    tmap: tile_map(lens, B, S) of the same lens (optional; lets the persistent kernel skip fully padded M-tiles).
+    tail_ws: tail_workspace(device) scratch (optional; lets the persistent kernel K-split its last partial round of tiles)."""
     if M is None:
         M = x.shape[0]
     if Cin is None:
@@ -114,6 +115,9 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
         assert ws is not None and ws.numel() >= ksplit * M * N and ws.dtype == torch.float32 and in_act == ACT_NONE and not accumulate
         _lib.call("fs2_conv_gemm_splitk", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), _p(ws),
                   ksplit, M, N, Cin, S, taps, dil, pad, act, slope, out_scale, dt(x), _stream())
+    elif tail_ws is not None:
+        _lib.call("fs2_conv_gemm_tail", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), _p(tail_ws),
+                  M, N, Cin, S, taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
     else:
         _lib.call("fs2_conv_gemm", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), M, N, Cin, S,
                   taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
@@ -124,6 +128,12 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
                                                 in_act, in_slope, dt(x)))
         PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, var, lens is not None, S))
     return out
+
+
+def tail_workspace(device):
+    """scratch for conv_gemm(..., tail_ws=): fs2_conv_gemm_tail_ws_bytes() bytes of f32 (one 256x128 slab per CU).  One per stream
+    of contraction launches (launches sharing it must not run concurrently)."""
+    return torch.empty(_lib.load().fs2_conv_gemm_tail_ws_bytes() // 4, device=device, dtype=torch.float32)
 
 
 def splitk_for(M, N, Cin, taps, dtype):

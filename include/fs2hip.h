@@ -57,6 +57,16 @@ int fs2_tile_map(const int32_t* lens, int B, int S, int rows, int32_t* out, fs2_
  * (optional). */
 int fs2_lens_prep(const int64_t* lens, int B, int S, int rows, int32_t* lens32, void* mask, float* count, int32_t* tile_map,
                   fs2_stream_t stream);
+/* fs2_conv_gemm with scratch for the persistent kernel's TAIL SPLIT: when the output tiles do not fill a whole number of rounds
+ * over the CUs, the last partial round is K-split (2 / 4 / 8 ways) so that it costs a fraction of a round instead of a whole
+ * one; the parts store f32 partial tiles into tail_ws and one more launch sums them and applies the epilogue.  tail_ws:
+ * fs2_conv_gemm_tail_ws_bytes() bytes, 16-byte aligned, any contents, not shared by launches that may run concurrently; NULL =
+ * fs2_conv_gemm.  Launches the persistent kernel does not take ignore it. */
+int fs2_conv_gemm_tail_ws_bytes(void);   /* a size, not a status */
+int fs2_conv_gemm_tail(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Y,
+                       long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin, int S,
+                       int taps, int dil, int pad, int act, float slope, int in_act, float in_slope, int accumulate,
+                       float out_scale, int dtype, fs2_stream_t stream);
 /* K-split form for few-tile, long-reduction contractions: `ksplit` workgroups per output tile store partial tiles into ws
  * (f32 scratch, ksplit x M x N, any contents), one more launch sums them and finalises (bias, activation, residual, bf16).
  * bf16 only, Cin % (64 ksplit) == 0; FS2_EINVAL for unsupported shapes (fall back to fs2_conv_gemm). */

@@ -98,19 +98,30 @@ def test_contraction_forward_and_dgrad_production_shapes(dev, dtype, name, Cin, 
     ref = torch.relu(conv_ref_gpu(x, wf, bias, S, pad))
     ref_l = ref.clone()
     ref_l[(torch.arange(S, device=dev).unsqueeze(0) >= lens_d.unsqueeze(1)).reshape(-1)] = 0
-    for use_lens, use_map in ((False, False), (True, False), (True, True)):
+    # ... and with the tail-split scratch (the persistent kernel K-splits its last partial round of tiles; slabs poisoned with NaN)
+    tws = ops.tail_workspace(dev).fill_(float("nan"))
+    for use_lens, use_map, tail in ((False, False, None), (True, False, None), (True, True, None), (False, False, tws), (True, True, tws)):
         y = ops.conv_gemm(x, wf, bias, S, taps=k, pad=pad, act=ops.ACT_RELU, lens=lens_d if use_lens else None,
-                          tmap=tmap if use_map else None)
-        assert_rounding_only(y, ref_l if use_lens else ref, dtype, (name, "fwd", use_lens, use_map))
+                          tmap=tmap if use_map else None, tail_ws=tail)
+        assert_rounding_only(y, ref_l if use_lens else ref, dtype, (name, "fwd", use_lens, use_map, tail is not None))
     # data gradient (tap-flipped pack, pad' = k-1-pad) with the fused residual add and with the ReLU gate
     dy = torch.randn(M, Cout, generator=g).to(dev).to(dtype)
     res = torch.randn(M, Cin, generator=g).to(dev).to(dtype)
     dref = conv_ref_gpu(dy, wd, None, S, (k - 1) - pad, lens=lens_d)
     valid = (torch.arange(S, device=dev).unsqueeze(0) < lens_d.unsqueeze(1)).reshape(-1, 1)
-    dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, res=res, lens=lens_d, tmap=tmap)
-    assert_rounding_only(dx, (dref + res.double()) * valid, dtype, (name, "dgrad+res"))
-    dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, act=ops.ACT_GATE, res=res, lens=lens_d, tmap=tmap)
-    assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)) * valid, dtype, (name, "dgrad gate"))
+    for tail in (None, tws):
+        dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, res=res, lens=lens_d, tmap=tmap, tail_ws=tail)
+        assert_rounding_only(dx, (dref + res.double()) * valid, dtype, (name, "dgrad+res", tail is not None))
+        dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, act=ops.ACT_GATE, res=res, lens=lens_d, tmap=tmap, tail_ws=tail)
+        assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)) * valid, dtype, (name, "dgrad gate", tail is not None))
+    if dtype == torch.bfloat16 and Cin % 64 == 0:
+        # every real-tile count from 1 to the full batch: whole rounds, 2- / 4- / 8-way tails and the all-tail launches
+        for nb in (1, 3, 7, 12, 20, 29, 37, 45):
+            Mq = nb * S
+            lq = lens_d[:nb].contiguous()
+            tq = ops.tile_map(lq, nb, S)
+            yq = ops.conv_gemm(x[:Mq], wf, bias, S, taps=k, pad=pad, act=ops.ACT_RELU, lens=lq, tmap=tq, tail_ws=tws)
+            assert_rounding_only(yq, ref_l[:Mq], dtype, (name, "fwd tail sweep", nb))
 
 
 @pytest.mark.parametrize("name,C,N,k,dil,S,Bq", [("rb C256 k7 d3", 256, 256, 7, 3, 7200, 8), ("rb C128 k11 d5", 128, 128, 11, 5, 57600, 4),

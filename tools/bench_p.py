@@ -28,6 +28,7 @@ def run():
     lens_by_S = {b["max_mel_len"]: b["mel_lens"].to(torch.int32).to(dev), 128: b["src_lens"].to(torch.int32).to(dev)}
     T = b["max_mel_len"]
     out = []
+    tws = ops.tail_workspace(dev)                                  # as the engine passes it (dev library: FS2_P_TKS=1 turns the split off)
     for (name, Cin, Cout, k, S) in SHAPES:
         S = T if S == 925 else S
         M = 48 * S
@@ -37,7 +38,7 @@ def run():
         w = (torch.randn(Cout, k, Cin, device=dev) / math.sqrt(Cin * k)).to(torch.bfloat16)
         bias = torch.randn(Cout, device=dev)
         y = torch.empty(M, Cout, device=dev, dtype=torch.bfloat16)
-        fn = lambda: ops.conv_gemm(x, w, bias, S, taps=k, pad=(k - 1) // 2, act=ops.ACT_RELU, lens=lens, tmap=tmap, out=y)
+        fn = lambda: ops.conv_gemm(x, w, bias, S, taps=k, pad=(k - 1) // 2, act=ops.ACT_RELU, lens=lens, tmap=tmap, out=y, tail_ws=tws)
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests/test_a_prodshape_gpu.py -x -q -m gpu -s 2>&1 | grep -E "rounding only\)|passed|failed|Error|error" | cut -c1-600 | tail -15 ) > gpurun_out/r02l_pytest.log 2>&1
-cat gpurun_out/r02l_pytest.log
+python tools/bench_p.py ab FS2_P_TKS=1 FS2_P_TKS=8 2>&1 | tail -16 > gpurun_out/r02n_bench_p2.md; cat gpurun_out/r02n_bench_p2.md
+bash tools/ab_step.sh > gpurun_out/r02n_ab.log 2>&1; cat gpurun_out/r02n_ab.log
