@@ -461,22 +461,30 @@ __device__ __forceinline__ void p_epilogue_part(float* slab, f32x16 (&acc)[2][4]
     }
 }
 
-// Tail tiles -> Y.  Grid (16, G): block (sub, b) looks at workgroup b of the contraction launch; when b ran part 0 of a split
-// tail tile it sums that tile's tks slabs (workgroups b .. of the same group) and applies bias / activation / residual / gate /
-// scale / padded-row zero - one thread per 8 consecutive columns of one row, 16 blocks per tile.  Every other block exits.
+// Tail tiles -> Y.  Grid (4, G/2): workgroups (.., i) look at contraction workgroup b = 2i (order 1: XCD i & 7, place 2 (i >> 3))
+// - a split tile's part 0 always sits on an even place; when b ran part 0 of a split tail tile they sum the tile's tks slabs
+// (the workgroups b .. of the same group) and apply bias / activation / residual / gate / scale / padded-row zero, one thread
+// per 8 consecutive columns of one row, 4 passes each over a quarter of the 256 x 128 tile.  Every other workgroup exits.
+// (16 workgroups per candidate - 4096 in all - cost 11 us per launch, most of it dispatching empty ones; one per candidate
+// walking 16 dependent passes was slower still.)
 template <int ACT>
 __global__ void __launch_bounds__(256) p_tail_finalize_kernel(ConvGemmArgs a, PSched sc) {
-    sc.b = blockIdx.y;
+    const int i = blockIdx.y;
+    sc.b = sc.order == 0 ? 2 * i : (i & 7) + 8 * (2 * (i >> 3));
+    if (sc.b >= sc.G) return;
     if (sc.tmap) { sc.n_real = sc.tmap[0]; sc.n_pad = sc.ntm - sc.n_real; }
     const PPlan p = p_plan(sc, sc.b);
     if (p.tks <= 1 || p.j >= p.tail * p.tks || (p.j % p.tks) != 0) return;
     int mi, nt, sp;
     p_pos(sc, p, p.R * p.Gg + p.j / p.tks, mi, nt, sp);
     const int mt = sc.tmap ? sc.tmap[1 + mi] : mi;
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // 0 .. 4095: (row, 8-column chunk) of the tile
+    const bool gate = a.act == FS2_ACT_GATE;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int idx = (blockIdx.x * 4 + pass) * 256 + threadIdx.x;      // 0 .. 4095: (row, 8-column chunk) of the tile
     const int r = idx >> 4, cn = (idx & 15) * 8;
     const int m = mt * 256 + r, n = nt * 128 + cn;
-    if (m >= a.M || n >= a.N) return;
+    if (m >= a.M || n >= a.N) continue;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < p.tks; ++q) {
         const int wg = sc.order == 0 ? sc.b + q : p.x + 8 * (p.j + q);
@@ -490,7 +498,6 @@ __global__ void __launch_bounds__(256) p_tail_finalize_kernel(ConvGemmArgs a, PS
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(v[e], a.slope);
-    const bool gate = a.act == FS2_ACT_GATE;
     if (a.R) {
         const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.R) + (size_t)m * a.ldr + n);
         const uint32_t* u = reinterpret_cast<const uint32_t*>(&rv);
@@ -508,6 +515,7 @@ __global__ void __launch_bounds__(256) p_tail_finalize_kernel(ConvGemmArgs a, PS
 #pragma unroll
     for (int e = 0; e < 4; ++e) ou[e] = padrow ? 0u : pack_bf16x2(v[2 * e] * a.out_scale, v[2 * e + 1] * a.out_scale);
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = o;
+  }
 }
 
 // leaky-ReLU on a landed activation fragment (HiFi-GAN's pre-activation convolutions; the LDS-DMA path cannot transform data on
@@ -930,5 +938,5 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
         const long chunks = (long)a.M * (a.N >> 3);
         FS2_ACT_DISPATCH(a.act, (splitk_finalize_kernel<ACT><<<(unsigned)((chunks + 255) / 256), 256, 0, stream>>>(a, ws, ks)));
     }
-    if (sc.tws) FS2_ACT_DISPATCH(a.act, (p_tail_finalize_kernel<ACT><<<dim3(16, (unsigned)sc.G), 256, 0, stream>>>(a, sc)));
+    if (sc.tws) FS2_ACT_DISPATCH(a.act, (p_tail_finalize_kernel<ACT><<<dim3(4, (unsigned)((sc.G + 1) / 2)), 256, 0, stream>>>(a, sc)));
 }

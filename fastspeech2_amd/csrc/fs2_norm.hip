@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(512) ln_bwd_kernel(LnBwdArgs a) {
             }
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(a.partial)[(size_t)FS2_LN_BWD_GRID * 2 * a.C] = (int)gridDim.x;
     // block reduction of dgamma / dbeta partials: 4 waves -> LDS -> wave 0 -> partial[block][2][C]
     // (a second tiny kernel sums the per-block partials: no same-address atomic storm)
 #pragma unroll
@@ -436,6 +437,7 @@ __global__ void __launch_bounds__(512) ln_bwd_c256_bf16_kernel(LnBwdArgs a) {
             if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.d2) + (size_t)row * 256 + c) = pack8f(dz);
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(a.partial)[(size_t)FS2_LN_BWD_GRID * 2 * 256] = (int)gridDim.x;
     // dgamma / dbeta partials of the workgroup: 16 half-waves -> LDS -> one column per thread -> partial[block][2][256]
     const int hw = w * 2 + hh;
     *reinterpret_cast<float4*>(&s_red[hw][c]) = make_float4(ag[0], ag[1], ag[2], ag[3]);
@@ -466,6 +468,7 @@ __global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float* __restr
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= 2 * C) return;
+    if (nblocks < 0) nblocks = reinterpret_cast<const int*>(partial)[(size_t)FS2_LN_BWD_GRID * 2 * C];   // deferred form: the count the backward kernel left
     const int per = (nblocks + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
@@ -485,7 +488,8 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
                           const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
                           float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
                           const uint64_t* seed_dev, int relu_bwd, int dtype, hipStream_t stream) {
-    FS2_CHECK_ARG(z && dout && gamma && mean && rstd && dgamma && dbeta, "ln_bwd: null pointer");
+    FS2_CHECK_ARG(z && dout && gamma && mean && rstd && ((dgamma != nullptr) == (dbeta != nullptr)), "ln_bwd: null pointer");
+    const bool reduce_now = dgamma != nullptr;              // both null: the caller runs fs2_ln_bwd_reduce later (any stream)
     FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * FS2_LN_MAXV, "ln_bwd: unsupported C=%d", C);
     // the wave-uniform early break in the reduction requires whole 256-channel groups
     FS2_CHECK_ARG(C % 256 == 0, "ln_bwd: C=%d must be a multiple of 256", C);
@@ -504,7 +508,7 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
         const int iters = fs2_cdiv(a.rows, 16 * FS2_LN_BWD_GRID);        // same trip count for every wave
         grid = fs2_cdiv(a.rows, 16 * iters);
         ln_bwd_c256_bf16_kernel<<<grid, 512, 0, stream>>>(a);
-        ln_bwd_reduce_kernel<<<dim3(fs2_cdiv(2 * C, 256), 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
+        if (reduce_now) ln_bwd_reduce_kernel<<<dim3(fs2_cdiv(2 * C, 256), 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
         FS2_CHECK_LAUNCH("ln_bwd");
         return FS2_OK;
     }
@@ -514,8 +518,18 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     if (dtype == FS2_F32) LN_BWD_NV(float);
     else if (dtype == FS2_BF16) LN_BWD_NV(bf16_t);
     else { fs2_set_error("ln_bwd: dtype"); return FS2_EDTYPE; }
-    ln_bwd_reduce_kernel<<<dim3(fs2_cdiv(2 * C, 256), 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
+    if (reduce_now) ln_bwd_reduce_kernel<<<dim3(fs2_cdiv(2 * C, 256), 32), 256, 0, stream>>>(partial_ws, grid, C, dgamma, dbeta);
     FS2_CHECK_LAUNCH("ln_bwd");
+    return FS2_OK;
+}
+
+// The second half of fs2_ln_bwd called with dgamma = dbeta = NULL: sums the per-workgroup partials that call left in partial_ws
+// (their count sits behind them) into dgamma / dbeta.  Nothing downstream of the LayerNorm reads the affine gradients before
+// the optimiser, so the engine runs this on its weight-gradient stream, off the data-gradient chain.
+extern "C" int fs2_ln_bwd_reduce(const float* partial_ws, int C, float* dgamma, float* dbeta, hipStream_t stream) {
+    FS2_CHECK_ARG(partial_ws && dgamma && dbeta && C > 0 && C % 256 == 0, "ln_bwd_reduce: bad arguments");
+    ln_bwd_reduce_kernel<<<dim3(fs2_cdiv(2 * C, 256), 32), 256, 0, stream>>>(partial_ws, -1, C, dgamma, dbeta);
+    FS2_CHECK_LAUNCH("ln_bwd_reduce");
     return FS2_OK;
 }
 
@@ -535,6 +549,7 @@ struct BnArgs {
     float* acc_dbeta; float* acc_dgamma;   // MODE 3 (optional): parameter gradients += sums (workgroup 0)
     float* clear;                // MODE 3 (optional): 2C floats zeroed by workgroup 0 (the NEXT call's sums)
     int M, C, cprp, rows_per_block, act;
+    int cblk;                    // channels per workgroup (grid.y walks the channel blocks); cprp * V when one workgroup spans the row
     float p; uint64_t seed; const uint64_t* seed_dev;
 };
 
@@ -569,8 +584,8 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
     const T* res = reinterpret_cast<const T*>(a.res);
     T* out = reinterpret_cast<T*>(a.out);
     const int chunk = threadIdx.x & (a.cprp - 1), rl = threadIdx.x / a.cprp, nrl = NT / a.cprp;
-    const int c = chunk * V;
-    const bool cok = c < a.C;
+    const int c = blockIdx.y * a.cblk + chunk * V;
+    const bool cok = chunk * V < a.cblk && c < a.C;
     uint64_t seed = a.seed;
     if (a.seed_dev) seed += *a.seed_dev;
     const float ik = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
@@ -654,20 +669,23 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
             row(r, v1, g1);
         }
     }
-    if (MODE == 0 || MODE == 2) {                      // reduce over the block's row lanes, then one atomic per channel
+    if (MODE == 0 || MODE == 2) {                      // tree over the block's row lanes in LDS, then one atomic per channel
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (pass) __syncthreads();
 #pragma unroll
             for (int k = 0; k < V; ++k) s_red[threadIdx.x * V + k] = pass ? a2[k] : a1[k];
             __syncthreads();
+            for (int st = nrl >> 1; st > 0; st >>= 1) {          // nrl = NT / cprp is a power of two
+                if (rl < st) {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) s_red[threadIdx.x * V + k] += s_red[(threadIdx.x + st * a.cprp) * V + k];
+                }
+                __syncthreads();
+            }
             if (rl == 0 && cok) {
 #pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    float t = 0.f;
-                    for (int j = 0; j < nrl; ++j) t += s_red[(j * a.cprp + chunk) * V + k];
-                    atomicAdd(a.sums + (pass ? a.C : 0) + c + k, t);
-                }
+                for (int k = 0; k < V; ++k) atomicAdd(a.sums + (pass ? a.C : 0) + c + k, s_red[threadIdx.x * V + k]);
             }
         }
     }
@@ -692,25 +710,35 @@ static int bn_vec(const BnArgs& a, int C, int dtype) {
     if (vec_env == 4) return 4;
     return (dtype == FS2_BF16 && C % 8 == 0 && (al & 15) == 0) ? 8 : 4;
 }
-static int bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks, int vec) {
-    int cpr = C / vec, cprp = 1;
+// cblk = 0: a workgroup spans whole rows (the streaming modes).  cblk > 0: a workgroup owns cblk channels and grid.y walks
+// the channel blocks - the REDUCING modes: every workgroup ends with one atomic per channel it owns, so the number of same-
+// address atomics is (row groups) x 2C; with whole-row workgroups 256 of them meant 262 144 atomics on 1024 addresses, about
+// half of the backward-sums pass (r02m: 54 us against 34 us for the dx pass that does the same arithmetic AND stores).  64-
+// channel blocks leave 32 row groups: 8x fewer atomics at the same number of workgroups, 128-byte row segments per wave.
+static dim3 bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks, int vec, int cblk = 0) {
+    static const int cblk_env = fs2_dev_env("FS2_BN_CBLK", 1);       // dev A/B: 0 = whole-row workgroups in the reducing modes too
+    if (!cblk_env) cblk = 0;
+    int cpr = (cblk > 0 && cblk < C ? cblk : C) / vec, cprp = 1;
     while (cprp < cpr) cprp <<= 1;
     a.cprp = cprp;
     a.M = M; a.C = C;
-    // ~want_blocks workgroups, each a whole number of row-lane sweeps
+    a.cblk = cprp * vec;
+    const int gy = fs2_cdiv(C, a.cblk);
+    // ~want_blocks workgroups in all, each a whole number of row-lane sweeps
     int nrl = nthreads / cprp;
-    int rpb = fs2_cdiv(M, want_blocks);
+    int rpb = fs2_cdiv(M, fs2_cdiv(want_blocks, gy));
     rpb = fs2_cdiv(rpb, nrl) * nrl;
     if (rpb < nrl) rpb = nrl;
     a.rows_per_block = rpb;
-    return fs2_cdiv(M, rpb);
+    return dim3((unsigned)fs2_cdiv(M, rpb), (unsigned)gy);
 }
 #define BN_LAUNCH(MODE, NT, grid) do { \
     if (dtype == FS2_F32) bn_rows_kernel<float, MODE, NT, 4><<<grid, NT, 0, stream>>>(a); \
     else if (dtype == FS2_BF16 && vec == 8) bn_rows_kernel<bf16_t, MODE, NT, 8><<<grid, NT, 0, stream>>>(a); \
     else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE, NT, 4><<<grid, NT, 0, stream>>>(a); \
     else { fs2_set_error("bn: dtype"); return FS2_EDTYPE; } } while (0)
-#define BN_REDUCE_BLOCKS 96        /* statistics: pure streaming, atomics-bound */
+#define BN_REDUCE_BLOCKS 256       /* statistics */
+#define BN_REDUCE_CBLK 64          /* channels per workgroup of the reducing modes */
 #define BN_BWD1_BLOCKS 256         /* backward sums: tanh + dropout hash per element -> needs every CU */
 
 // stats[0..C) = sum, stats[C..2C) = sum of squared deviations  (caller zeroes stats first)
@@ -720,7 +748,7 @@ extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype
     BnArgs a = {};
     a.x = x; a.sums = stats;
     const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
-    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec);
+    dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
     else bn_stats_fix_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats, M, C);
@@ -776,7 +804,7 @@ extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, float* running
     BnArgs a = {};
     a.x = x; a.sums = stats_ws;
     const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
-    int grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec);
+    dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
     else bn_fix_finalize_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
@@ -803,7 +831,7 @@ extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* 
     a.x = x; a.res = res; a.out = out; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.act = act; a.p = p;
     a.seed = seed; a.seed_dev = seed_dev;
     const int vec = bn_vec(a, C, dtype);
-    int grid = bn_geometry(a, M, C, 256, 2048, vec);
+    dim3 grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(1, 256, grid);
     FS2_CHECK_LAUNCH("bn_apply");
     return FS2_OK;
@@ -822,7 +850,7 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
     int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
-    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec);
+    dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
     BN_LAUNCH(2, 1024, grid);
     vec = bn_vec(a, C, dtype);
     grid = bn_geometry(a, M, C, 256, 2048, vec);
@@ -843,7 +871,7 @@ extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean
     a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
     int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
-    int grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec);
+    dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
     BN_LAUNCH(2, 1024, grid);
     a.acc_dbeta = dbeta_acc; a.acc_dgamma = dgamma_acc; a.clear = sums_next;
     vec = bn_vec(a, C, dtype);

@@ -65,6 +65,8 @@ class Engine:
         self._side_stream = None
         self._side = None
         self._side_keep = []
+        self._ln_pending = []
+        self.defer_ln_reduce = True
         self._pack_pending = False
         self._tmaps = {}
         self._bn_ws = {}
@@ -273,12 +275,30 @@ class Engine:
             return
         side.wait_stream(self._main)            # dy was produced on the main stream
         with ops.pinned_stream(side):           # (no allocation happens inside: only the launch needs the side stream)
+            self._ln_flush()
             ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
         self._side_keep.append((dy, x))         # the caching allocator must not recycle them before the join
+
+    def _ln_bwd(self, z, dout, gamma, lens, mean, rstd, gw, gb, B, S, **kw):
+        """LayerNorm backward; with a side stream the affine-gradient reduction (a 5 us launch nothing on the data-gradient chain
+        waits for) is deferred to the next weight-gradient section of that stream."""
+        if self._side is None or not self.defer_ln_reduce:
+            return ops.ln_bwd(z, dout, gamma, lens, mean, rstd, gw, gb, B, S, **kw)
+        d1, d2, ws = ops.ln_bwd(z, dout, gamma, lens, mean, rstd, gw, gb, B, S, defer=True, **kw)
+        self._ln_pending.append((ws, z.shape[-1], gw, gb))
+        return d1, d2
+
+    def _ln_flush(self):
+        """(inside a side-stream section that already waits for the main stream)"""
+        for ws, C, gw, gb in self._ln_pending:
+            ops.ln_bwd_reduce(ws, C, gw, gb)
+            self._side_keep.append(ws)
+        self._ln_pending = []
 
     def _side_begin(self):
         """fork: weight gradients of this backward go to the side stream (FS2_SIDE_STREAM=0 keeps one stream)."""
         self._side_keep = []
+        self._ln_pending = []
         self._main = torch.cuda.current_stream()
         if self._pack_pending:                  # data-gradient packs were written on the side stream during forward
             self._main.wait_stream(self._side_stream)
@@ -293,6 +313,10 @@ class Engine:
     def _side_join(self):
         """join: everything queued on the side stream happens-before whatever the main stream does next."""
         if self._side is not None:
+            if self._ln_pending:
+                self._side.wait_stream(self._main)
+                with ops.pinned_stream(self._side):
+                    self._ln_flush()
             self._main.wait_stream(self._side)
         self._side_keep = []
 
@@ -321,7 +345,7 @@ class Engine:
         ks = self.tc["conv_kernel_size"]
         a, f = pre + "slf_attn.", pre + "pos_ffn."
         p = sv.p
-        dz2, dy2 = ops.ln_bwd(sv.z2, dout, self.P[f + "layer_norm.weight"], lens, sv.mean2, sv.rstd2,
+        dz2, dy2 = self._ln_bwd(sv.z2, dout, self.P[f + "layer_norm.weight"], lens, sv.mean2, sv.rstd2,
                               G[f + "layer_norm.weight"], G[f + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
                               p_pre=p, **_seed_kw("seed_pre", sv.site + 1, seed_dev))
         if dy2 is None:
@@ -332,7 +356,7 @@ class Engine:
         dhid = self._dgemm(W, f + "w_2", dy2, S, taps=ks[1], pad=(ks[1] - 1) // 2, act=ACT_GATE, res=sv.hid, lens=l2)
         self._wgrad(G[f + "w_1.weight"], G[f + "w_1.bias"], dhid, sv.h, S, taps=ks[0], pad=(ks[0] - 1) // 2, lens=l2)
         dh = self._dgemm(W, f + "w_1", dhid, S, taps=ks[0], pad=(ks[0] - 1) // 2, res=dz2, lens=lens)
-        dz1, dy1 = ops.ln_bwd(sv.z1, dh, self.P[a + "layer_norm.weight"], lens, sv.mean1, sv.rstd1,
+        dz1, dy1 = self._ln_bwd(sv.z1, dh, self.P[a + "layer_norm.weight"], lens, sv.mean1, sv.rstd1,
                               G[a + "layer_norm.weight"], G[a + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
                               p_pre=p, **_seed_kw("seed_pre", sv.site, seed_dev))
         if dy1 is None:
@@ -368,12 +392,12 @@ class Engine:
         S, p = sv.S, sv.p
         dn2 = ops.rowdot_bwd(sv.n2, self.P[pre + "linear_layer.weight"], dpred, sv.lens, G[pre + "linear_layer.weight"],
                              G[pre + "linear_layer.bias"], B, S)
-        _, dc2 = ops.ln_bwd(sv.c2, dn2, self.P[cl + "layer_norm_2.weight"], None, sv.m2, sv.r2, G[cl + "layer_norm_2.weight"],
+        _, dc2 = self._ln_bwd(sv.c2, dn2, self.P[cl + "layer_norm_2.weight"], None, sv.m2, sv.r2, G[cl + "layer_norm_2.weight"],
                             G[cl + "layer_norm_2.bias"], B, S, want_d1=False, want_d2=True, p_post=p,
                             relu_bwd=True, **_seed_kw("seed_post", sv.site + 1, seed_dev))
         self._wgrad(G[cl + "conv1d_2.conv.weight"], G[cl + "conv1d_2.conv.bias"], dc2, sv.n1, S, taps=k, pad=1)
         dn1 = self._dgemm(W, cl + "conv1d_2", dc2, S, taps=k, pad=1)
-        _, dc1 = ops.ln_bwd(sv.c1, dn1, self.P[cl + "layer_norm_1.weight"], None, sv.m1, sv.r1, G[cl + "layer_norm_1.weight"],
+        _, dc1 = self._ln_bwd(sv.c1, dn1, self.P[cl + "layer_norm_1.weight"], None, sv.m1, sv.r1, G[cl + "layer_norm_1.weight"],
                             G[cl + "layer_norm_1.bias"], B, S, want_d1=False, want_d2=True, p_post=p,
                             relu_bwd=True, **_seed_kw("seed_post", sv.site, seed_dev))
         self._wgrad(G[cl + "conv1d_1.conv.weight"], G[cl + "conv1d_1.conv.bias"], dc1, sv.x, S, taps=k, pad=(k - 1) // 2)

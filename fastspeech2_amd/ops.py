@@ -218,14 +218,23 @@ def ln_fwd(y, res, gamma, beta, lens, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, p_p
 
 
 def ln_bwd(z, dout, gamma, lens, mean, rstd, dgamma, dbeta, B, S, want_d1=True, want_d2=False, d1_add=None, p_pre=0.0,
-           seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False, seed_dev=None):
+           seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False, seed_dev=None, defer=False):
+    """defer=True: the affine-gradient reduction is NOT launched; returns (d1, d2, ws) and the caller runs
+    ln_bwd_reduce(ws, C, dgamma, dbeta) later (any stream ordered after this call; ws must stay alive until then)."""
     C = z.shape[-1]
     d1 = torch.empty_like(z) if want_d1 else None
     d2 = torch.empty_like(z) if want_d2 else None
-    ws = torch.empty(1024 * 2 * C, device=z.device, dtype=torch.float32)
+    ws = torch.empty(1024 * 2 * C + 4, device=z.device, dtype=torch.float32)
     _lib.call("fs2_ln_bwd", _p(z), _p(dout), _p(gamma), _p(lens), _p(mean), _p(rstd), _p(d1_add), _p(d1), _p(d2),
-              _p(dgamma), _p(dbeta), _p(ws), B, S, C, p_pre, seed_pre, p_post, seed_post, _p(seed_dev), int(relu_bwd), dt(z), _stream())
+              _p(None if defer else dgamma), _p(None if defer else dbeta), _p(ws), B, S, C, p_pre, seed_pre, p_post, seed_post,
+              _p(seed_dev), int(relu_bwd), dt(z), _stream())
+    if defer:
+        return d1, d2, ws
     return d1, d2
+
+
+def ln_bwd_reduce(ws, C, dgamma, dbeta):
+    _lib.call("fs2_ln_bwd_reduce", _p(ws), C, _p(dgamma), _p(dbeta), _stream())
 
 
 # ------------------------------------------------------------------ batch norm

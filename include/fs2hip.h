@@ -115,12 +115,15 @@ int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, 
                float* mean, float* rstd, int B, int S, int C, float eps, float p_pre, uint64_t seed_pre, float p_post,
                uint64_t seed_post, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 /* d1 = dz (+ d1_add), d2 = dz * dropmask_pre * (relu_bwd ? z>0 : 1); dgamma/dbeta += column sums.
- * partial_ws: caller workspace of FS2_LN_BWD_GRID*2*C floats (per-block partial sums, reduced by a 2nd launch). */
+ * partial_ws: caller workspace of FS2_LN_BWD_GRID*2*C + 4 floats (per-block partial sums and their count, reduced by a 2nd
+ * launch).  dgamma = dbeta = NULL defers that launch: call fs2_ln_bwd_reduce(partial_ws, ...) later, on any stream ordered
+ * after this call, before partial_ws is reused. */
 #define FS2_LN_BWD_GRID 1024
 int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
                const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
                float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, const uint64_t* seed_dev,
                int relu_bwd, int dtype, fs2_stream_t stream);
+int fs2_ln_bwd_reduce(const float* partial_ws, int C, float* dgamma /*+=*/, float* dbeta /*+=*/, fs2_stream_t stream);
 
 /* ---- BatchNorm1d (+tanh, +dropout) of PostNet: transformer/Layers.py:129-137 ------------------------ */
 int fs2_bn_stats(const void* x, float* stats /*2C, zeroed*/, int M, int C, int dtype, fs2_stream_t stream);

@@ -15,6 +15,8 @@ def one():
     dev = torch.device("cuda:0")
     torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     model, loss_fn, opt, b, _, _ = bench.build(a, dev, 0, 1)
+    if os.environ.get("AB_LN_DEFER") == "0":                 # tool-level switch (the product reads no environment)
+        model._engine.defer_ln_reduce = False
     step, _ = bench.make_step(model, loss_fn, opt, b, None)
     for _ in range(6):
         step()

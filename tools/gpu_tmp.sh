@@ -1,5 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python tools/bench_p.py ab FS2_P_TKS=1 FS2_P_TKS=8 2>&1 | tail -16 > gpurun_out/r02n_bench_p2.md; cat gpurun_out/r02n_bench_p2.md
-bash tools/ab_step.sh > gpurun_out/r02n_ab.log 2>&1; cat gpurun_out/r02n_ab.log
+( timeout 600 python -m pytest tests/test_a_prodshape_gpu.py -x -q -m gpu -k "contraction" 2>&1 | tail -3 ) > gpurun_out/r02q_pytest.log 2>&1
+tail -2 gpurun_out/r02q_pytest.log | cut -c1-300
+bash tools/ab_step.sh > gpurun_out/r02q_ab.log 2>&1; cat gpurun_out/r02q_ab.log
+python tools/bench_p.py 2>&1 | tail -1 | tr ';' '\n' | grep -E "dgrad"
