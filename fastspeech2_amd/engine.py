@@ -70,7 +70,9 @@ class Engine:
         self._pack_pending = False
         self._tmaps = {}
         self._bn_ws = {}
-        self._tail_ws = None
+        self._tail_ws = [None, None]
+        self._on_side = False
+        self.concurrent_branches = True
 
     # ------------------------------------------------------------------ dropout stream
     _SEED_INC = 0x632BE59BD9B4E019 & 0x7FFFFFFFFFFFFFFF
@@ -257,10 +259,53 @@ class Engine:
                              tail_ws=self._tail_workspace(dy.device))
 
     def _tail_workspace(self, device):
-        """scratch of the persistent kernel's tail split (one per engine: its contractions run on one stream, in order)."""
-        if self._tail_ws is None and device.type == "cuda":
-            self._tail_ws = ops.tail_workspace(device)
-        return self._tail_ws
+        """scratch of the persistent kernel's tail split: one per stream the engine launches contractions on (launches that
+        share one must not run concurrently)."""
+        if device.type != "cuda":
+            return None
+        k = 1 if self._on_side else 0
+        if self._tail_ws[k] is None:
+            self._tail_ws[k] = ops.tail_workspace(device)
+        return self._tail_ws[k]
+
+    class _Branch:
+        """`with engine._branch():` - the enclosed launches AND allocations go to the side stream, which first waits for
+        everything queued on the main stream so far.  Used for the variance predictors: their outputs feed only the loss
+        (forward) and their input gradients are needed only where the variance adaptor's backward adds them up, so 3 x ~9
+        small latency-bound launches leave the critical chain in each direction and run beside the decoder's big kernels.
+        Allocations inside belong to the side stream's pool (temporaries are recycled in that stream's order); a tensor that
+        crosses back to the main stream is handed over with an event and record_stream."""
+
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            e = self.eng
+            e._side_stream.wait_stream(e._branch_main)
+            self.ctx = torch.cuda.stream(e._side_stream)
+            self.ctx.__enter__()
+            self.pin = ops.pinned_stream(e._side_stream)
+            self.pin.__enter__()
+            e._on_side = True
+            return self
+
+        def __exit__(self, *exc):
+            e = self.eng
+            e._on_side = False
+            self.pin.__exit__(*exc)
+            self.ctx.__exit__(*exc)
+
+    def _branch(self):
+        return Engine._Branch(self)
+
+    def _branch_ok(self):
+        """side stream available for branch concurrency (creates it)"""
+        if not (self.use_side_stream and self.concurrent_branches) or self.device.type != "cuda":
+            return False
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        self._branch_main = torch.cuda.current_stream()
+        return True
 
     def _wgrad(self, gw, gb, dy, x, S, taps=1, pad=0, lens=None):
         """weight (+ bias) gradient of one contraction.  Weight gradients are OFF the critical path of backward (nothing
@@ -466,18 +511,33 @@ class Engine:
 
         # ---- variance adaptor (model/modules.py:102-158)
         p_control, e_control, d_control = st.ctl
-        logd, sv.dur = self._pred_fwd(W, "duration", x, src_lens32, B, L, p_vp, seed_dev, 100, keep)
         pitch_phone = m.pitch_feature_level == "phoneme_level"
         energy_phone = m.energy_feature_level == "phoneme_level"
         p_pred = e_pred = None
-        if pitch_phone:
+        # teacher-forced training step: the predictions feed only the loss, the embeddings come from the targets -> the three
+        # predictors run on the side stream beside the rest of the forward pass (joined before the outputs are returned)
+        sv.branch = bool(keep and pitch_phone and energy_phone and st.p_t is not None and st.e_t is not None and st.d_t is not None
+                         and self._branch_ok())
+        if sv.branch:
+            with self._branch():
+                logd, sv.dur = self._pred_fwd(W, "duration", x, src_lens32, B, L, p_vp, seed_dev, 100, keep)
+                p_pred, sv.pitch = self._pred_fwd(W, "pitch", x, src_lens32, B, L, p_vp, seed_dev, 102, keep)
+            x, sv.pitch_idx = ops.bucket_embed_add_fwd(x, st.p_t.contiguous().view(-1), 1.0, P["variance_adaptor.pitch_bins"],
+                                                       P["variance_adaptor.pitch_embedding.weight"])
+            with self._branch():
+                e_pred, sv.energy = self._pred_fwd(W, "energy", x, src_lens32, B, L, p_vp, seed_dev, 104, keep)
+            x, sv.energy_idx = ops.bucket_embed_add_fwd(x, st.e_t.contiguous().view(-1), 1.0, P["variance_adaptor.energy_bins"],
+                                                        P["variance_adaptor.energy_embedding.weight"])
+        else:
+            logd, sv.dur = self._pred_fwd(W, "duration", x, src_lens32, B, L, p_vp, seed_dev, 100, keep)
+        if pitch_phone and not sv.branch:
             p_pred, sv.pitch = self._pred_fwd(W, "pitch", x, src_lens32, B, L, p_vp, seed_dev, 102, keep)
             if st.p_t is None:
                 p_pred = p_pred * p_control if p_control != 1.0 else p_pred
             vals = st.p_t if st.p_t is not None else p_pred
             x, sv.pitch_idx = ops.bucket_embed_add_fwd(x, vals.contiguous().view(-1), 1.0, P["variance_adaptor.pitch_bins"],
                                                        P["variance_adaptor.pitch_embedding.weight"])
-        if energy_phone:
+        if energy_phone and not sv.branch:
             e_pred, sv.energy = self._pred_fwd(W, "energy", x, src_lens32, B, L, p_vp, seed_dev, 104, keep)
             if st.e_t is None:   # NB reference passes p_control here (model/modules.py:124)
                 e_pred = e_pred * p_control if p_control != 1.0 else e_pred
@@ -558,6 +618,9 @@ class Engine:
             h = h_out
         post = h
 
+        if sv.branch:                               # the predictions (side stream) are outputs
+            self._branch_main.wait_stream(self._side_stream)
+            self._pack_pending = False              # (that join covers the data-gradient packs too)
         n_mel = mel.shape[1]
         mel_o = (ops.cast(mel, torch.float32) if cdt != torch.float32 else mel).view(B, Tdec, n_mel)
         post_o = (ops.cast(post, torch.float32) if cdt != torch.float32 else post).view(B, Tdec, n_mel)
@@ -592,6 +655,23 @@ class Engine:
             t = t.contiguous().view(shape)
             return ops.cast(t, cdt) if t.dtype != cdt else t
 
+        # variance predictors' backward: beside the PostNet / decoder backward, on the side stream (first in its queue).
+        # d(x3) -> [energy embedding] -> + energy predictor -> [pitch embedding] -> + pitch and duration predictors
+        ev_e = ev_pd = dv_e = dv_pd = None
+        if sv.branch and self._side is not None:
+            self._branch_main = self._main
+            with self._branch():
+                if de is not None:
+                    dv_e = self._pred_bwd(W, G, "energy", sv.energy, de.contiguous(), B, seed_dev, None)
+                ev_e = self._side_stream.record_event()
+                if dp is not None:
+                    dv_pd = self._pred_bwd(W, G, "pitch", sv.pitch, dp.contiguous(), B, seed_dev, None)
+                if dlogd is not None:
+                    dv_pd = self._pred_bwd(W, G, "duration", sv.dur, dlogd.contiguous(), B, seed_dev, dv_pd)
+                ev_pd = self._side_stream.record_event()
+            for t in (dv_e, dv_pd):
+                if t is not None:
+                    t.record_stream(self._main)
         dmel = to_c(dmel, (B * T, n_mel))
         dpost = to_c(dpost, (B * T, n_mel))
         zeros = None
@@ -637,16 +717,26 @@ class Engine:
                 dy = self._pred_bwd(W, G, "pitch", sv.pitch, dpp, B, seed_dev, dy)
         dx = ops.lr_gather_bwd(dy, sv.cum, B, L, T)
         # ---- phoneme-level variance branches
-        if sv.energy_phone:
+        if ev_e is not None:                        # the predictors' input gradients were computed on the side stream
             ops.bucket_embed_bwd(sv.energy_idx, dx, G["variance_adaptor.energy_embedding.weight"])
-            if dee is not None:
-                dx = self._pred_bwd(W, G, "energy", sv.energy, dee, B, seed_dev, dx)
-        if sv.pitch_phone:
+            if dv_e is not None:
+                self._main.wait_event(ev_e)
+                dx = ops.add(dx, dv_e)
             ops.bucket_embed_bwd(sv.pitch_idx, dx, G["variance_adaptor.pitch_embedding.weight"])
-            if dpp is not None:
-                dx = self._pred_bwd(W, G, "pitch", sv.pitch, dpp, B, seed_dev, dx)
-        if dlogd is not None:
-            dx = self._pred_bwd(W, G, "duration", sv.dur, dlogd.contiguous(), B, seed_dev, dx)
+            if dv_pd is not None:
+                self._main.wait_event(ev_pd)
+                dx = ops.add(dx, dv_pd)
+        else:
+            if sv.energy_phone:
+                ops.bucket_embed_bwd(sv.energy_idx, dx, G["variance_adaptor.energy_embedding.weight"])
+                if dee is not None:
+                    dx = self._pred_bwd(W, G, "energy", sv.energy, dee, B, seed_dev, dx)
+            if sv.pitch_phone:
+                ops.bucket_embed_bwd(sv.pitch_idx, dx, G["variance_adaptor.pitch_embedding.weight"])
+                if dpp is not None:
+                    dx = self._pred_bwd(W, G, "pitch", sv.pitch, dpp, B, seed_dev, dx)
+            if dlogd is not None:
+                dx = self._pred_bwd(W, G, "duration", sv.dur, dlogd.contiguous(), B, seed_dev, dx)
         if m.speaker_emb is not None:
             ops.rowvec_bwd(dx, G["speaker_emb.weight"], sv.speakers, B, L)
         # ---- encoder

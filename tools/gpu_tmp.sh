@@ -1,7 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( timeout 600 python -m pytest tests/test_a_prodshape_gpu.py -x -q -m gpu -k "contraction" 2>&1 | tail -3 ) > gpurun_out/r02q_pytest.log 2>&1
-tail -2 gpurun_out/r02q_pytest.log | cut -c1-300
-bash tools/ab_step.sh > gpurun_out/r02q_ab.log 2>&1; cat gpurun_out/r02q_ab.log
-python tools/bench_p.py 2>&1 | tail -1 | tr ';' '\n' | grep -E "dgrad"
+( timeout 900 python -m pytest tests/test_model_gpu.py tests/test_a_prodshape_gpu.py tests/test_checkpoint_gpu.py -x -q -m gpu -k "not contraction and not vocoder and not weight_gradient" 2>&1 | tail -5 ) > gpurun_out/r02r_pytest.log 2>&1
+tail -3 gpurun_out/r02r_pytest.log | cut -c1-600
+bash tools/ab_step.sh > gpurun_out/r02r_ab.log 2>&1; cat gpurun_out/r02r_ab.log
