@@ -318,9 +318,11 @@ def pmc_traffic(kernel_substr):
         return None
     path = cands[-1]                                      # newest round's passes
     k = json.load(open(path))["kernels"]
-    n = sum(v["launches_per_step"] for name, v in k.items() if kernel_substr in name)
-    b = sum(v["launches_per_step"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for name, v in k.items()
-            if kernel_substr in name)
+    # "conv_gemm_p_kernel<false>" names the ONE_TAP = false instantiations, whatever template arguments follow in rocprof's name
+    pat = kernel_substr[:-1] if kernel_substr.endswith(">") else kernel_substr
+    hit = lambda name: name.startswith(pat) or (" " + pat) in name
+    n = sum(v["launches_per_step"] for name, v in k.items() if hit(name))
+    b = sum(v["launches_per_step"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for name, v in k.items() if hit(name))
     return {"bytes_per_launch": round(b / n), "source": "profiles/%s (rocprofv3 --pmc, separate passes)" % os.path.basename(path)} if n else None
 
 

@@ -32,7 +32,7 @@ def test_bench_line_contract(dev):
     assert r["kernel"].startswith("conv_gemm_p_kernel<false>") and r["launches_per_step"] >= 16 and r["avg_launch_us"] > 0
     assert 0 < r["frac_valid_rows"] <= r["frac"]                           # FLOPs of valid rows only (fully padded tiles are skipped)
     assert abs(r["gflop_per_launch"] * r["launches_per_step"] / r["kernel_ms_per_step"] - r["achieved"]) < 0.02 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"]["bytes_per_launch"] > 0
+    assert r["traffic"] is not None and r["traffic"]["bytes_per_launch"] > 0          # profiles/*_pmc_traffic.json travels with the repo
     # tamper evidence + measurement quality: the shipped library, no development variables, the timed
     # window repeated and the median reported, the reference's own arithmetic (fp32) as a secondary figure of the same line
     cfg = d["config"]
