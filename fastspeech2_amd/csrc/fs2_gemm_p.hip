@@ -27,6 +27,13 @@
 //   * the same without any lgkmcnt(0) at the step boundary (counter read one slice early, release published from inside the
 //     next slice): no faster (253 us), and it exposed how fragile asm-tracked LDS reads are across code the compiler may
 //     re-register (stale copies of in-flight fragments at tile boundaries).
+//   * (r02t) an EARLY fragment schedule - every fragment register re-read for the k-slice TWO ahead right behind its last MFMA
+//     (same twelve registers, 11-13 MFMA slots between a read and its use instead of 7-8) with the loaders publishing a slot one
+//     K-step earlier to make the look-ahead legal: correct (all production-shape tests), but SLOWER - k=9 FFN conv 249 vs 205 us,
+//     PostNet k=5 129 vs 109 us (profiles/r02t_early_schedule_bench_p.txt).  Publishing earlier costs one step of DMA prefetch
+//     depth (2 K-steps = 40 KB per CU in flight instead of 3), and the loader side is latency-bound (Little's law: ~10 TB/s of
+//     L2 -> LDS traffic at ~2 us needs ~78 KB per CU in flight; the rings hold 60): the fragment-read latency it hides is worth
+//     less than the DMA depth it gives up.  LDS is full (158 of 160 KB), so the depth cannot be bought back.
 // Ablations of THIS version (profiles/r02a_bench_p.md, k=9 FFN conv, 215 us): loaders + barriers alone 97 us, + MFMAs 150 us,
 // + fragment reads 215 us; epilogue 25 us of it.
 // Synchronisation: one raw s_barrier per K-step (64 deep) publishes the slot the loaders filled D-1 steps earlier and

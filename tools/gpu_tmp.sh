@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests/test_model_gpu.py tests/test_a_prodshape_gpu.py tests/test_checkpoint_gpu.py -x -q -m gpu -k "not contraction and not vocoder and not weight_gradient" 2>&1 | tail -5 ) > gpurun_out/r02r_pytest.log 2>&1
-tail -3 gpurun_out/r02r_pytest.log | cut -c1-600
-bash tools/ab_step.sh > gpurun_out/r02r_ab.log 2>&1; cat gpurun_out/r02r_ab.log
+( timeout 600 python -m pytest tests/test_a_prodshape_gpu.py -x -q -m gpu -k "contraction or vocoder or splitk" 2>&1 | tail -5 ) > gpurun_out/r02t_pytest.log 2>&1
+tail -4 gpurun_out/r02t_pytest.log | cut -c1-500
+python tools/bench_p.py 2>&1 | tail -1 | tr ';' '\n' > gpurun_out/r02t_bench_p.txt; cat gpurun_out/r02t_bench_p.txt
