@@ -239,7 +239,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;                        // m: running maximum of s * scale * log2(e)
+    const float sc2 = scale * 1.4426950408889634f;
 
     uint4 tk0, tk1, tk2, tk3, tv0, tv1, tv2, tv3;
     TILE_LOAD_REGS(tk, K, ld, 0, S - 1);
@@ -277,33 +278,43 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
                 c0 = n0; c1 = n1;
             }
         }
+        // Softmax bookkeeping in the log2 domain (p = exp2(s * scale * log2 e - m): one fma + one v_exp_f32 per score), the
+        // key-padding mask only on the sequence's last tile, and a LAZY running maximum: the accumulators are rescaled only
+        // when some query's maximum grew by more than 2^8 - after the first tiles that is almost never, and a rescale costs
+        // 16 cross-lane permutes + 64 multiplies per wave and tile (r02s PMC: 15.7 VALU instructions per MFMA made this kernel
+        // VALU-bound 2:1).  A stale maximum only scales p and l by the same factor <= 2^8: o / l is unchanged.
+        if (k0 + 64 > len) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + crow(r, h2) >= len) s[kb][r] = -INFINITY;
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc2;                       // scale > 0: the maximum of the raw scores, scaled once
+        if (__builtin_amdgcn_ballot_w64(mx > m + 8.f) != 0ull) {           // wave-uniform; always taken on the first tile (m = -inf)
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+            m = mn;
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = s[kb][r] * scale;
-                if (k0 + kb * 32 + crow(r, h2) >= len) v = -INFINITY;
-                s[kb][r] = v;
-                mx = fmaxf(mx, v);
+                float ar = __shfl(alpha, crow(r, h2), 64);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float mn = fmaxf(m, mx);
-        float alpha = __expf(m - mn);
+        }
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[kb][r] = __expf(s[kb][r] - mn); rs += s[kb][r]; }
+            for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc2, -m)); rs += s[kb][r]; }
         rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        m = mn;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float ar = __shfl(alpha, crow(r, h2), 64);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
-        }
+        l += rs;
         {   // P V: the four V fragments of the next 16-key group are fetched while the current group is multiplied
             bf16x8 cv[4], nv[4];
 #pragma unroll
@@ -333,7 +344,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
         __syncthreads();
     }
     float linv = l > 0.f ? 1.f / l : 0.f;
-    if (h2 == 0 && myq < S) lse_o[myq] = (l > 0.f) ? m + __logf(l) : 0.f;
+    if (h2 == 0 && myq < S) lse_o[myq] = (l > 0.f) ? m * 0.6931471805599453f + __logf(l) : 0.f;      // natural-log lse for the backward
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float li = __shfl(linv, crow(r, h2), 64);
@@ -395,12 +406,16 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
 
     // threads 0..63 carry lse, 64..127 delta of query (tile start + tid & 63); a query >= len gets lse = +inf -> p = 0
     const float* ld_src = tid < 64 ? lse_b : del_b;
+    // (lse travels in the log2 domain: p = exp2(s * scale * log2 e - lse * log2 e) is one fma + one v_exp_f32 per score)
+    const float sc2 = scale * 1.4426950408889634f;
     auto load_ld = [&](int q0) -> float {
         int q = q0 + (tid & 63);
         float v = ld_src[min(q, S - 1)];
+        if (tid < 64) v *= 1.4426950408889634f;
         if (q >= len) v = tid < 64 ? INFINITY : 0.f;
         return v;
     };
+
     uint4 tq0, tq1, tq2, tq3, td0, td1, td2, td3;
     float tl = 0.f;
     TILE_LOAD_REGS(tq, Q, ld, 0, S - 1);
@@ -458,9 +473,9 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
             for (int r = 0; r < 16; ++r) {
                 const float lq = reinterpret_cast<const float*>(&l4[r >> 2])[r & 3];
                 const float dq_ = reinterpret_cast<const float*>(&d4[r >> 2])[r & 3];
-                const float p = __expf(s[r] * scale - lq) * key_ok;          // lq = +inf for q >= len -> exp(-inf) = 0
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -lq)) * key_ok;   // lq = +inf for q >= len -> exp2(-inf) = 0
                 pv[r] = p;
-                dsv[r] = p * (dp[r] - dq_) * scale;
+                dsv[r] = p * (dp[r] - dq_);                                  // (the softmax scale multiplies dK once, at the store)
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -485,7 +500,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
         if (key < S) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                dK[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dk[nb][r]);
+                dK[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dk[nb][r] * scale);
                 dV[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dv[nb][r]);
             }
         }
@@ -519,6 +534,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
     const bool q_ok = myq < len;
     float my_lse = 0.f, my_del = 0.f;
     if (myq < S) { my_lse = lse[((size_t)b * H + h) * S + myq]; my_del = delta[((size_t)b * H + h) * S + myq]; }
+    // log2 domain (one fma + one v_exp_f32 per score); a padded query gets lse = +inf -> p = 0 without a mask multiply
+    const float sc2 = scale * 1.4426950408889634f;
+    const float my_lse2 = q_ok ? my_lse * 1.4426950408889634f : INFINITY;
     bf16x8 qf[8], df[8];
     load_row_frags(qf, Q + (size_t)min(myq, S - 1) * ld, h2, myq < S);
     load_row_frags(df, dO + (size_t)min(myq, S - 1) * ldo, h2, myq < S);
@@ -565,12 +583,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 }
             }
             float dsv[16];
-            const float qok = q_ok ? 1.f : 0.f;
+            const bool tail = k0 + kb * 32 + 32 > len;                     // block-uniform: the only key block with padded keys
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kb * 32 + crow(r, h2);
-                const float p = __expf(s[r] * scale - my_lse) * (key < len ? qok : 0.f);
-                dsv[r] = p * (dp[r] - my_del) * scale;
+                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -my_lse2));
+                if (tail && k0 + kb * 32 + crow(r, h2) >= len) p = 0.f;
+                dsv[r] = p * (dp[r] - my_del);                                  // (the softmax scale multiplies dQ once, at the store)
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -591,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
         int q = q0 + w * 32 + crow(r, h2);
         if (q < S) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) dQ[(size_t)q * ld + nb * 32 + fl] = f32_to_bf16(dq[nb][r]);
+            for (int nb = 0; nb < 4; ++nb) dQ[(size_t)q * ld + nb * 32 + fl] = f32_to_bf16(dq[nb][r] * scale);
         }
     }
 }
