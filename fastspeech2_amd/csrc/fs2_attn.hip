@@ -507,9 +507,12 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
     }
 }
 
+// (also computes delta[q] = sum_d dO[q][d] O[q][d] for its queries - a lane already holds half of its query's dO row - and
+// writes it for the dK/dV kernel, which therefore runs AFTER this one: the separate delta launch, 12 us per layer, is gone)
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                                  const bf16_t* __restrict__ ctx,
                                                                   const bf16_t* __restrict__ dctx, long ldo,
-                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  const float* __restrict__ lse, float* __restrict__ delta,
                                                                   bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,
                                                                   int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
@@ -524,6 +527,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
             int r = i >> 5, c = (i & 31) * 4;
             if (q0 + r < S) st4<bf16_t>(dQ + (size_t)(q0 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
         }
+        if (tid < 128 && q0 + tid < S) delta[((size_t)b * H + h) * S + q0 + tid] = 0.f;      // (never read: queries >= len)
         return;
     }
     const bf16_t* Q = qkv + rowbase * ld + h * DK;
@@ -533,13 +537,30 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
     const int myq = q0 + w * 32 + fl;
     const bool q_ok = myq < len;
     float my_lse = 0.f, my_del = 0.f;
-    if (myq < S) { my_lse = lse[((size_t)b * H + h) * S + myq]; my_del = delta[((size_t)b * H + h) * S + myq]; }
+    if (myq < S) my_lse = lse[((size_t)b * H + h) * S + myq];
     // log2 domain (one fma + one v_exp_f32 per score); a padded query gets lse = +inf -> p = 0 without a mask multiply
     const float sc2 = scale * 1.4426950408889634f;
     const float my_lse2 = q_ok ? my_lse * 1.4426950408889634f : INFINITY;
     bf16x8 qf[8], df[8];
     load_row_frags(qf, Q + (size_t)min(myq, S - 1) * ld, h2, myq < S);
     load_row_frags(df, dO + (size_t)min(myq, S - 1) * ldo, h2, myq < S);
+    {   // delta of my query from the dO fragments just loaded (this lane: d = 16 s + 8 h2 + e; the other half-wave has the rest)
+        bf16x8 of[8];
+        load_row_frags(of, ctx + (rowbase + (size_t)min(myq, S - 1)) * ldo + h * DK, h2, myq < S);
+        float acc = 0.f;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const uint4 ov = __builtin_bit_cast(uint4, of[st]), dv_ = __builtin_bit_cast(uint4, df[st]);
+            const uint32_t* ou = reinterpret_cast<const uint32_t*>(&ov);
+            const uint32_t* du = reinterpret_cast<const uint32_t*>(&dv_);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc += __uint_as_float(ou[e] << 16) * __uint_as_float(du[e] << 16) + __uint_as_float(ou[e] & 0xffff0000u) * __uint_as_float(du[e] & 0xffff0000u);
+        }
+        acc += __shfl_xor(acc, 32, 64);
+        my_del = acc;                                        // (rows >= S load zeros)
+        if (h2 == 0 && myq < S) delta[((size_t)b * H + h) * S + myq] = my_del;
+    }
     f32x16 dq[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -873,9 +894,9 @@ extern "C" int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
         attn_bwd_dkv_kernel<float><<<grid, 256, dyn, stream>>>((const float*)qkv, ld, (const float*)dctx, ldo, lse, delta, (float*)dqkv, lens, S, H, scale);
         attn_bwd_dq_kernel<float><<<grid, 256, 0, stream>>>((const float*)qkv, ld, (const float*)dctx, ldo, lse, delta, (float*)dqkv, lens, S, H, scale);
     } else if (dtype == FS2_BF16) {
-        attn_delta_kernel<bf16_t><<<fs2_cdiv(rows * H, 4), 256, 0, stream>>>((const bf16_t*)ctx, (const bf16_t*)dctx, delta, rows, S, H);
+        // dQ first: it also produces delta (row sums of dO * O) for the dK/dV kernel
+        attn_bwd_dq_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)ctx, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
         attn_bwd_dkv_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
-        attn_bwd_dq_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
     } else { fs2_set_error("attn_bwd: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("attn_bwd");
     return FS2_OK;
