@@ -1566,8 +1566,12 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     // of atomics (r01k sweep: k=9 FFN 294 -> 250 us at 5 splits x 48 tiles, PostNet k=5 201 -> 158 us at 8 x 32).
     // r02 same-box A/B of the WHOLE step (tools/ab_env.py): these launches run on the side stream next to the data-gradient
     // chain, and fewer, longer workgroups disturb it less than the split depth that is fastest in isolation (one-tap 384 ->
-    // 192, tap-group kernels 256 -> 128 workgroups: 10.16 -> 9.90 ms per step; 96 and below lose again)
-    int wg_target = units < 256 ? 192 : (NT == 1 ? 192 : (NW == 8 ? 128 : 768));
+    // 192, tap-group kernels 256 -> 128 workgroups: 10.16 -> 9.90 ms per step; 96 and below lose again).  Re-tuned at the end of
+    // round 2, after the variance predictors and the LayerNorm reductions moved to the side stream and the attention kernels got
+    // shorter: tap-group kernels at 192 (k=9 FFN 4 splits x 48 tiles, PostNet k=5 6 x 32) instead of 128 (2 / 4 splits):
+    // 9.75 -> 9.25 ms and 9.3 -> 9.05 ms on two boxes; 160 ... 224 are within 0.3 %, 240+ (5 splits of the k=9 FFN) and 96
+    // lose 2 % (profiles/r02y_ab_env*.log)
+    int wg_target = units < 256 ? 192 : (NT == 1 ? 192 : (NW == 8 ? 192 : 768));
     int min_ups = NT == 1 ? 8 : ((tiles <= 8 && units >= 512) ? 16 : 4);
     if (wg_env) wg_target = wg_env;
     static const int wg_env1 = fs2_dev_env("FS2_WGRAD_WGS1", 0), wg_env3 = fs2_dev_env("FS2_WGRAD_WGS3", 0);
