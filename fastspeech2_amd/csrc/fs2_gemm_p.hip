@@ -97,7 +97,7 @@ struct PSched {
 // Schedule of one workgroup GROUP (order 0: all G workgroups and all tiles; order 1: the G/8 workgroups of one XCD and the
 // tiles of the M-tiles mi = x mod 8): R full rounds, then `tail` tiles left over, each split `tks` ways (1 = not split).
 struct PPlan { int Gg, j, x, T, R, tail, tks; };
-__device__ __forceinline__ PPlan p_plan(const PSched& s, int b) {
+__host__ __device__ __forceinline__ PPlan p_plan(const PSched& s, int b) {
     PPlan p;
     if (s.order == 0) { p.Gg = s.G; p.j = b; p.x = 0; p.T = s.n_real * s.ntn * s.ks; }
     else {
@@ -116,7 +116,7 @@ __device__ __forceinline__ PPlan p_plan(const PSched& s, int b) {
     return p;
 }
 // position in the group's unit list -> (index into the real-M-tile list, N-tile, uniform K-split index)
-__device__ __forceinline__ void p_pos(const PSched& s, const PPlan& p, int pos, int& mi, int& nt, int& sp) {
+__host__ __device__ __forceinline__ void p_pos(const PSched& s, const PPlan& p, int pos, int& mi, int& nt, int& sp) {
     if (s.order == 0) {
         const int rest = pos / s.ks;
         sp = pos - rest * s.ks;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void p_pos(const PSched& s, const PPlan& p, int pos, 
 }
 // k-th unit of workgroup s.b: index into the real-M-tile list, N-tile, first Cin chunk and chunk count, tail part count (1 =
 // a whole tile); false when the workgroup has no k-th unit
-__device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt, int& kc0, int& nkc, int& np) {
+__host__ __device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt, int& kc0, int& nkc, int& np) {
     const PPlan p = p_plan(s, s.b);
     int pos, part = 0;
     np = 1;
@@ -861,6 +861,27 @@ static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream
     static Fs2DevOnce once;
     once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_p_kernel<ONE_TAP, WIDE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
     conv_gemm_p_kernel<ONE_TAP, WIDE, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
+}
+
+// The persistent kernel's schedule, evaluated on the HOST (the same p_plan / p_unit the device runs): the units of workgroup b of
+// a launch with n_real real M-tiles, ntn N-tiles, G workgroups, tile order `order`, uniform K-split ks over nkc Cin chunks and a
+// tail split of at most tks_max (1 = none).  out receives up to 64 x {mi, nt, kc0, nkc, parts}; returns the unit count.  Test aid
+// (tests/test_schedule_cpu.py proves every tile's chunk range is covered exactly once for any n_real).
+extern "C" int fs2_conv_gemm_p_units(int n_real, int ntn, int G, int order, int ks, int nkc, int tks_max, int b, int* out) {
+    FS2_CHECK_ARG(out && n_real >= 0 && ntn > 0 && G > 0 && ks > 0 && nkc > 0 && nkc % ks == 0 && b >= 0 && b < G && (order == 0 || G % 8 == 0),
+                  "conv_gemm_p_units: bad arguments");
+    PSched s = {};
+    s.G = G; s.b = b; s.ntm = n_real; s.ntn = ntn; s.n_real = n_real; s.n_pad = 0; s.tmap = nullptr;
+    s.ks = ks; s.nkc_u = nkc / ks; s.ws = nullptr; s.order = order;
+    s.tws = tks_max > 1 ? reinterpret_cast<float*>(16) : nullptr; s.tks_max = tks_max;
+    int n = 0;
+    for (int k = 0; k < 64; ++k) {
+        int mi, nt, kc0, nk, np;
+        if (!p_unit(s, k, mi, nt, kc0, nk, np)) break;
+        out[5 * n] = mi; out[5 * n + 1] = nt; out[5 * n + 2] = kc0; out[5 * n + 3] = nk; out[5 * n + 4] = np;
+        ++n;
+    }
+    return n;
 }
 
 // bytes of tail-split scratch fs2_conv_gemm_tail wants: one 256x128 f32 slab per workgroup of a full-chip launch

@@ -67,6 +67,11 @@ int fs2_conv_gemm_tail(const void* X, long ldx, const void* Wpacked, const float
                        long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin, int S,
                        int taps, int dil, int pad, int act, float slope, int in_act, float in_slope, int accumulate,
                        float out_scale, int dtype, fs2_stream_t stream);
+/* Test aid: the persistent kernel's unit list of workgroup b, evaluated on the host by the same schedule functions the device
+ * runs (n_real real M-tiles, ntn N-tiles, G workgroups, tile order 0 / 1, uniform K-split ks over nkc Cin chunks, tail split of
+ * at most tks_max, 1 = none).  out: up to 64 x {real-tile index, N-tile, first chunk, chunk count, tail parts}.  Returns the unit
+ * count (a count, not a status); negative on bad arguments. */
+int fs2_conv_gemm_p_units(int n_real, int ntn, int G, int order, int ks, int nkc, int tks_max, int b, int* out);
 /* K-split form for few-tile, long-reduction contractions: `ksplit` workgroups per output tile store partial tiles into ws
  * (f32 scratch, ksplit x M x N, any contents), one more launch sums them and finalises (bias, activation, residual, bf16).
  * bf16 only, Cin % (64 ksplit) == 0; FS2_EINVAL for unsupported shapes (fall back to fs2_conv_gemm). */

@@ -1,0 +1,82 @@
+"""Host-side proof of the persistent contraction kernel's schedule (fs2_gemm_p.hip: p_plan / p_unit, the same functions the device
+runs, reached through fs2_conv_gemm_p_units): for ANY number of real M-tiles - it is only known on the device - the workgroups'
+unit lists cover every output tile's reduction range exactly once, tail parts sit where p_tail_finalize_kernel looks for them,
+and no workgroup holds more than the 64 units its two-VGPR table can carry.  No GPU needed: pure host code of libfs2hip.so."""
+import ctypes
+import random
+
+import pytest
+
+from fastspeech2_amd import _lib
+
+
+def units_of(n_real, ntn, G, order, ks, nkc, tks_max, b):
+    lib = _lib.load()
+    buf = (ctypes.c_int * (64 * 5))()
+    n = lib.fs2_conv_gemm_p_units(n_real, ntn, G, order, ks, nkc, tks_max, b, ctypes.cast(buf, ctypes.c_void_p))
+    assert n >= 0, lib.fs2_last_error().decode()
+    return [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+
+
+def check(n_real, ntn, G, order, ks, nkc, tks_max):
+    cover = {}
+    parts_at = {}
+    for b in range(G):
+        us = units_of(n_real, ntn, G, order, ks, nkc, tks_max, b)
+        assert len(us) <= 64
+        for i, (mi, nt, kc0, nk, np_) in enumerate(us):
+            assert 0 <= mi < n_real and 0 <= nt < ntn and nk > 0 and 0 <= kc0 and kc0 + nk <= nkc, (b, us[i])
+            cover.setdefault((mi, nt), []).append((kc0, nk))
+            if np_ > 1:
+                assert i == len(us) - 1 and ks == 1 and np_ <= tks_max and nk * np_ == nkc, (b, us[i])      # a tail part is a workgroup's LAST unit
+                parts_at.setdefault((mi, nt), []).append((b, kc0 // nk, np_))
+            else:
+                assert nk == nkc // ks
+    assert len(cover) == n_real * ntn                                             # every tile ...
+    for tile, rs in cover.items():
+        rs.sort()
+        pos = 0
+        for kc0, nk in rs:                                                        # ... exactly once over its whole reduction
+            assert kc0 == pos, (tile, rs)
+            pos += nk
+        assert pos == nkc, (tile, rs)
+    for tile, ps in parts_at.items():                                             # where the finalize kernel expects the slabs
+        ps.sort(key=lambda t: t[1])
+        np_ = ps[0][2]
+        assert [q for _, q, _ in ps] == list(range(np_)) and all(p[2] == np_ for p in ps)
+        b0 = ps[0][0]
+        if order == 0:
+            assert b0 % 2 == 0 and b0 % np_ == 0 and [b for b, _, _ in ps] == [b0 + q for q in range(np_)]
+        else:
+            x, j0 = b0 & 7, b0 >> 3
+            assert j0 % np_ == 0 and [b for b, _, _ in ps] == [x + 8 * (j0 + q) for q in range(np_)]
+    return len(parts_at)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_every_tile_is_covered_exactly_once(order):
+    rng = random.Random(11 + order)
+    split_seen = 0
+    for G in (256, 64):
+        for ntn in (1, 2, 4, 8):
+            for nkc, tks_max in ((16, 8), (16, 4), (8, 2), (4, 4), (4, 1), (9, 1)):
+                for n_real in sorted({0, 1, 7, G // ntn, G // ntn + 1} | {rng.randrange(1, 200) for _ in range(6)}):
+                    if n_real * ntn > 64 * G:
+                        continue
+                    split_seen += check(n_real, ntn, G, order, 1, nkc, tks_max)
+    assert split_seen > 100                                                       # the sweep did exercise split tails
+
+
+def test_uniform_ksplit_units():
+    for order in (0, 1):
+        for ks, nkc in ((2, 16), (4, 16), (2, 8)):
+            for n_real, ntn in ((24, 2), (150, 2), (7, 1)):
+                check(n_real, ntn, 256, order, ks, nkc, 1)
+
+
+def test_production_shapes_tail_plan():
+    """the launches the bench's step actually splits: k=9 data gradient (~165 real tiles x 2, 16 chunks) -> 4- or 2-way tails;
+    the encoder's (24 x 2 tiles on 256 workgroups) -> all tail, 4 parts each"""
+    assert check(165, 2, 256, 0, 1, 16, 8) == 165 * 2 - 256
+    us = [units_of(24, 2, 256, 0, 1, 16, 8, b) for b in range(256)]
+    assert sum(len(u) for u in us) == 192 and all(u[0][4] == 4 for u in us if u)
