@@ -17,6 +17,10 @@ def one():
     model, loss_fn, opt, b, _, _ = bench.build(a, dev, 0, 1)
     if os.environ.get("AB_LN_DEFER") == "0":                 # tool-level switch (the product reads no environment)
         model._engine.defer_ln_reduce = False
+    if os.environ.get("AB_BRANCH") == "0":
+        model._engine.concurrent_branches = False
+    # (stream priorities: torch.cuda.Stream.priority_range() is (0, -1) on this stack - the step runs on -1, the side stream on 0;
+    # there is no lower level to try)
     step, _ = bench.make_step(model, loss_fn, opt, b, None)
     for _ in range(6):
         step()
