@@ -1065,6 +1065,13 @@ static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* b
     return FS2_OK;
 }
 
+// Test aid: column position of logical column c (0..127) inside a 128-float epilogue staging row for the given output dtype
+// (fs2_tile_col128).  tests/test_schedule_cpu.py checks the layout against the ds_read_b128 / ds_write_b32 service groups.
+extern "C" int fs2_stage_tile_col(int c, int dtype) {
+    FS2_CHECK_ARG(c >= 0 && c < 128 && (dtype == FS2_F32 || dtype == FS2_BF16), "stage_tile_col: bad arguments");
+    return dtype == FS2_BF16 ? fs2_tile_col128<bf16_t>(c) : fs2_tile_col128<float>(c);
+}
+
 extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
                              long ldy, const int32_t* lens, const int32_t* tile_map, int M, int N, int Cin, int S, int taps, int dil,
                              int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale, int dtype,

@@ -67,6 +67,9 @@ int fs2_conv_gemm_tail(const void* X, long ldx, const void* Wpacked, const float
                        long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin, int S,
                        int taps, int dil, int pad, int act, float slope, int in_act, float in_slope, int accumulate,
                        float out_scale, int dtype, fs2_stream_t stream);
+/* Test aid: position of logical column c (0..127) in a 128-float epilogue staging row of the 128x128 / ring / skinny kernels for
+ * output dtype FS2_F32 / FS2_BF16 (a position, not a status; negative on bad arguments). */
+int fs2_stage_tile_col(int c, int dtype);
 /* Test aid: the persistent kernel's unit list of workgroup b, evaluated on the host by the same schedule functions the device
  * runs (n_real real M-tiles, ntn N-tiles, G workgroups, tile order 0 / 1, uniform K-split ks over nkc Cin chunks, tail split of
  * at most tks_max, 1 = none).  out: up to 64 x {real-tile index, N-tile, first chunk, chunk count, tail parts}.  Returns the unit
