@@ -9,9 +9,15 @@ SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS)) $(OBJ)/fs2_api.o
 LIB   := fastspeech2_amd/libfs2hip.so
 
-all: $(LIB)
+AIDLIB := tests/aids/libfs2_testaid.so
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h
+all: $(LIB) $(AIDLIB)
+
+# host-only test aids over the kernels' own schedule source (include/fs2hip_testaid.h); not part of the product library
+$(AIDLIB): tests/aids/fs2_testaid.cpp $(CSRC)/fs2_sched.h include/fs2hip_testaid.h
+	g++ -O2 -std=c++17 -shared -fPIC -I$(CSRC) -Iinclude -o $@ tests/aids/fs2_testaid.cpp
+
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h $(CSRC)/fs2_sched.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -23,7 +29,7 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) $(AIDLIB)
 
 .PHONY: all clean
 
@@ -32,7 +38,7 @@ clean:
 DEVOBJ := build/obj_dev
 DEVOBJS := $(patsubst $(CSRC)/%.hip,$(DEVOBJ)/%.o,$(SRCS)) $(DEVOBJ)/fs2_api.o
 DEVLIB := fastspeech2_amd/libfs2hip_dev.so
-$(DEVOBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h
+$(DEVOBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h $(CSRC)/fs2_sched.h
 	@mkdir -p $(DEVOBJ)
 	$(HIPCC) $(HIPFLAGS) -DFS2_DEV -c $< -o $@
 $(DEVOBJ)/fs2_api.o: $(CSRC)/fs2_api.cpp

@@ -10,9 +10,12 @@ value = sum of valid mel frames over all ranks and K steps / max-over-ranks wall
 
 The same JSON line carries
   roofline     — the dominant kernel (conv_gemm MFMA contraction): algorithmic FLOPs of its launches / their HIP-event
-                 durations, measured in an instrumented replay of the same step right after the timed region;
-  cpu_baseline — the CPU oracle (a port of the reference algorithm, oracle/fs2_oracle.py) timed on this host's
-                 cores on a bounded sample (B=4, 2 steps) of the same workload.  Reported, not a target.
+                 durations, measured in an instrumented replay of the same step right after the timed region; plus
+                 `wgrad_family`: the weight-gradient kernels of the same replay (the largest block of device time);
+  cpu_baseline — the CPU oracle (a port of the reference algorithm, oracle/fs2_oracle.py; the reference tree itself is not
+                 on the GPU box) timed on this host's cores on a bounded sample of the same workload: B=4, BASELINE.md §2's
+                 10 steps with 2 discarded, at the best of a torch-thread sweep.  Reported, not a target;
+  config.synth — the second half of BASELINE's metric, batch-synthesis RTF on a val.txt-shaped workload (N = 1 only).
 """
 import argparse
 import json
@@ -34,7 +37,7 @@ def train_flop_per_frame(args):
     return (TRAIN_FLOP_PER_FRAME + (args.dec_layers - 4) * 20.05e6 + (4.1e6 if args.frame_level else 0.0))
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -65,7 +68,16 @@ def parse():
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 (the reference's own arithmetic) step time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-synth", action="store_true", help="train mode: skip the batch-synthesis RTF object (config.synth)")
+    ap.add_argument("--cpu-threads", default="8,16,32,64", help="torch thread counts the CPU baseline sweeps (those <= cpu_count)")
+    a = ap.parse_args(argv)
+    argv = sys.argv if argv is None else argv
+    if a.mode == "synth":                        # one pass over the val.txt-shaped batches by default (64 batches of 8)
+        if "--steps" not in argv:
+            a.steps = 64
+        if "--warmup" not in argv:
+            a.warmup = 64
+    return a
 
 
 def dev_environment():
@@ -101,13 +113,17 @@ def build(args, device, rank, world, dtype=None):
     model._ensure_flat(device)
     model._engine.use_side_stream = bool(args.side_stream)
     if libri:
-        # one length-bucketed batch out of a LibriTTS-like pool: log-normal phoneme counts (median 49, p95 ~176), the
-        # pool is sorted and this rank takes the bucket at the 75th percentile (what BucketedBatchSampler deals per step)
+        # a LibriTTS-like pool (log-normal phoneme counts: median ~49, p95 ~176) dealt by the REAL sampler of train.py
+        # (fastspeech2_amd/data.BucketedBatchSampler: shuffled windows of 4 steps, sorted by length inside a window, each
+        # step's world*batch items dealt card-wise): every rank gets ITS OWN bucket of the same step - similar but not
+        # identical length profiles, so the line's per-rank times show what the slowest rank costs
+        from fastspeech2_amd.data import BucketedBatchSampler
         g = torch.Generator().manual_seed(99)
-        pool = torch.clamp(torch.exp(torch.randn(4096, generator=g) * 0.78 + 3.89), 5, 250).long()
-        pool, _ = torch.sort(pool, descending=True)
-        L = int(pool[1024])
-        b = synthetic_batch(1234 + rank, args.batch, L, dur_lo=4, dur_hi=10, min_len_frac=float(pool[1024 + args.batch]) / L, n_speaker=2456)
+        pool = torch.clamp(torch.exp(torch.randn(8192, generator=g) * 0.78 + 3.89), 5, 250).long()
+        sampler = BucketedBatchSampler(pool.numpy(), args.batch, world_size=world, rank=rank, group_size=4, shuffle=True, seed=1234)
+        steps = list(iter(sampler))
+        idxs = steps[len(steps) // 3]                        # one fixed step of the epoch (every rank picks the same step)
+        b = synthetic_batch(1234 + rank, 0, 0, dur_lo=4, dur_hi=10, n_speaker=2456, src_lens=pool[idxs].tolist())
     else:
         # every rank gets the SAME length profile (what the length-bucketed card-wise sampler of fastspeech2_amd/data.py deals
         # per step, so no rank waits for another's longer batch) with its OWN contents (phoneme ids, mels, pitch, energy)
@@ -152,8 +168,46 @@ def make_step(model, loss_fn, opt, b, exchange):
     return step, fwd_bwd
 
 
+def capture_graph(model, opt, fwd_bwd):
+    """hipGraph of forward + loss + backward + clip/Adam (lr / bias corrections are read from device memory).  Returns
+    (graph, static_loss, replay) - `replay()` advances the host-side optimiser state and replays.  The caller must have set
+    model._engine.device_seed = True BEFORE its warm-up steps: the dropout position then lives in device memory and is bumped
+    by a kernel inside the graph (every replay draws fresh masks); an eager-mode capture would bake one step's seed into the
+    kernel arguments.  BatchNorm's backward workspaces are cleared inside the capture (engine.py), so replays do not
+    accumulate into each other."""
+    assert model._engine.device_seed, "set model._engine.device_seed = True before warm-up and capture"
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        static_loss = fwd_bwd()
+        opt.apply_update(zero_grad=True)
+    torch.cuda.synchronize()
+
+    def replay():
+        opt.current_step += 1
+        opt._adam_step += 1
+        lr = opt.init_lr * opt._get_lr_scale()
+        b1, b2 = opt.betas
+        opt.set_hyper(lr, 1 - b1 ** opt._adam_step, 1 - b2 ** opt._adam_step)
+        graph.replay()
+
+    return graph, static_loss, replay
+
+
+def _thread_counts(args):
+    n = os.cpu_count() or 1
+    cand = sorted({int(t) for t in str(args.cpu_threads).split(",") if t.strip()})
+    cand = [t for t in cand if t <= n] or [min(n, 8)]
+    return cand
+
+
 def cpu_baseline(args):
-    """CPU oracle (port of the reference algorithm) on a bounded sample: B=4, same L/T, fwd+loss+bwd+clip+Adam."""
+    """CPU oracle (port of the reference algorithm) on a bounded sample: B=4, same L/T, fwd+loss+bwd+clip+Adam.
+    Protocol: the torch thread count is SWEPT (a B=4 step oversubscribed onto every
+    logical CPU is slower than on 8-32 threads), 3 steps each with the first discarded; then 10 steps at the best count, 2
+    discarded, MEDIAN of the remaining 8.  kind = "port": /root/reference is not shipped to the GPU box; the port follows it
+    line by line (oracle/fs2_oracle.py) and runs at the unmodified reference's speed (same box, 8 cores: 0.80-1.03 vs 0.94-1.4 s)."""
     from fastspeech2_amd import synthetic as configs
     from oracle import fs2_oracle as O
     from fastspeech2_amd.synthetic import synthetic_batch
@@ -170,8 +224,8 @@ def cpu_baseline(args):
     opt = torch.optim.Adam(params, betas=(0.9, 0.98), eps=1e-9)
     b = synthetic_batch(1234, 4, args.phonemes, dur_lo=4, dur_hi=10, min_len_frac=0.75)
     bn = {k: v for k, v in sd.items() if "running_" in k}
-    times = []
-    for it in range(3):
+
+    def one():
         t0 = time.perf_counter()
         out = O.fastspeech2_forward(sd, mcfg, pcfg, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"],
                                     b["mel_lens"], b["max_mel_len"], b["pitches"], b["energies"], b["durations"],
@@ -181,30 +235,87 @@ def cpu_baseline(args):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
-        times.append(time.perf_counter() - t0)
-    t = min(times[1:])
+        return time.perf_counter() - t0
+
+    prev = torch.get_num_threads()
+    sweep = {}
+    try:
+        for nt in _thread_counts(args):
+            torch.set_num_threads(nt)
+            ts = [one() for _ in range(3)]
+            sweep[nt] = sum(ts[1:]) / 2
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        ts = sorted([one() for _ in range(10)][2:])
+        t = 0.5 * (ts[3] + ts[4])                            # median of 8
+    finally:
+        torch.set_num_threads(prev)
     frames = int(b["mel_lens"].sum())
-    return {"value": round(frames / t, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle train step, B=4, L={args.phonemes}, T={b['max_mel_len']}, best of 2 timed steps ({t:.2f} s/step), "
-                      f"host cpu_count={os.cpu_count()}"}
+    return {"value": round(frames / t, 1), "unit": "mel-frames/s", "cores": best, "kind": "port",
+            "sample": f"oracle train step (port of the reference; the reference tree is not on the GPU box), B=4, L={args.phonemes}, "
+                      f"T={b['max_mel_len']}, {best} torch threads (best of sweep "
+                      + ", ".join(f"{k}: {v:.2f} s" for k, v in sorted(sweep.items()))
+                      + f"), 10 steps, 2 discarded, median of 8 = {t:.3f} s/step, host cpu_count={os.cpu_count()}"}
 
 
-def synth_main(args):
-    """BASELINE metric part 2: batch-synthesis real-time factor = wall(acoustic model + HiFi-GAN + int16) / audio seconds
-    on LJSpeech-shaped synthetic text batches (random-init weights; duration-predictor bias set so that ~7 frames per
-    phoneme are produced).  One process per GPU, replicas only (no collective)."""
+def synth_cpu_baseline(args, lens8, threads):
+    """the oracle's batch synthesis (acoustic model + HiFi-GAN + int16) of ONE val.txt-shaped batch of 8 on the host cores."""
     import math
     from fastspeech2_amd import synthetic as configs
     from fastspeech2_amd.synthetic import synthetic_batch
     from fastspeech2_amd.model import FastSpeech2
     from fastspeech2_amd import hifigan, utils
-    lib_used = dev_environment()
+    from oracle import fs2_oracle as O
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch.distributed as dist
-    device = init_rank(world, local_rank)
+    pcfg, mcfg = configs.make_configs(dec_layers=4, enc_layers=4)
+    torch.manual_seed(1234)
+    model = FastSpeech2(pcfg, mcfg)
+    with torch.no_grad():
+        model.variance_adaptor.duration_predictor.linear_layer.bias.fill_(math.log(8.0))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    h = hifigan.AttrDict(utils.HIFIGAN_V1)
+    voc = hifigan.Generator(h)
+    vsd = O.remove_weight_norm_sd({k: v.clone() for k, v in voc.state_dict().items()})
+    b = synthetic_batch(4321, 0, 0, src_lens=lens8, sort=False)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                out = O.fastspeech2_forward(sd, mcfg, pcfg, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], training=False,
+                                            dropout=False)
+                wav = O.hifigan_forward(vsd, h, out[1].transpose(1, 2))
+                pcm = O.pcm16(wav)
+            times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+    t = min(times)
+    audio_s = float(out[9].sum()) * 256 / 22050.0
+    return {"value": round(t / audio_s, 5), "unit": "s wall per s audio", "cores": threads, "kind": "port",
+            "sample": f"oracle acoustic model + HiFi-GAN + int16 on the first val.txt-shaped batch (8 utterances, {audio_s:.1f} s of audio), "
+                      f"best of 2 ({t:.2f} s), {threads} torch threads"}
+
+
+SYNTH_NAMES = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel",
+               5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)"}
+
+
+def synth_measure(args, device, rank, world, steps, warmup, want_roofline):
+    """BASELINE metric part 2: batch-synthesis real-time factor = wall(acoustic model + HiFi-GAN + int16 + PCM to host) / audio
+    seconds.  Workload = the reference's `synthesize.py --mode batch --source val.txt` (synthesize.py:197-199): the 512
+    utterances of LJSpeech val.txt in FILE ORDER, 8 per batch, unsorted, each batch padded to its own longest utterance - the
+    phoneme counts are the real ones (fastspeech2_amd/workloads/ljspeech_val_phonemes.json, made from the reference by
+    tools/make_val_shape.py), the phoneme ids are random, weights are random-init with the duration predictor's bias set so that
+    ~7 frames per phoneme come out.  A step = one batch of 8; with N ranks the 64 batches are dealt round-robin (replicas only).
+    Returns a dict of raw numbers (this rank's)."""
+    import math
+    from fastspeech2_amd import synthetic as configs
+    from fastspeech2_amd.synthetic import synthetic_batch, val_phoneme_counts
+    from fastspeech2_amd.model import FastSpeech2
+    from fastspeech2_amd import hifigan, utils, ops
+
     pcfg, mcfg = configs.make_configs(dec_layers=4, enc_layers=4)
     torch.manual_seed(1234)
     model = FastSpeech2(pcfg, mcfg, compute_dtype=args.dtype)
@@ -216,43 +327,47 @@ def synth_main(args):
     voc.remove_weight_norm()
     voc.to(device)
     B = args.synth_batch
-    b = synthetic_batch(4321 + rank, B, args.phonemes, min_len_frac=0.5)
-    batch = ([f"u{i}" for i in range(B)], None, b["speakers"].to(device), b["texts"].to(device), b["src_lens"].to(device),
-             b["max_src_len"])
+    counts = val_phoneme_counts()
+    groups = [counts[i:i + B] for i in range(0, len(counts), B)][rank::world]
+    batches = []
+    for gi, lens in enumerate(groups):
+        b = synthetic_batch(4321 + 64 * rank + gi, 0, 0, src_lens=lens, sort=False)
+        batches.append(([f"u{i}" for i in range(len(lens))], None, b["speakers"].to(device), b["texts"].to(device),
+                        b["src_lens"].to(device), b["max_src_len"]))
 
-    def step():
+    def step(i):
+        batch = batches[i % len(batches)]
         with torch.no_grad():
             out = model(*batch[2:])
             wavs = utils.synth_samples(batch, out, voc, mcfg, pcfg, None, write=False)   # includes the D2H of the PCM
         return out, wavs
 
-    for _ in range(args.warmup):
-        out, wavs = step()
+    for i in range(warmup):
+        step(i)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
+    audio_samples, frames = 0, 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, wavs = step()
+    for i in range(steps):
+        out, wavs = step(i)
+        audio_samples += sum(len(w) for w in wavs)            # (host lists: the PCM is already on the host)
+        frames += int(sum(len(w) for w in wavs)) // 256
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    audio_s = sum(len(w) for w in wavs) / 22050.0 * args.steps
-    tt = torch.tensor([dt, audio_s, float(out[9].sum().item()) * args.steps], device=device, dtype=torch.float64)
-    if world > 1:
-        tmax = tt[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt)
-        tt[0] = tmax[0]
-    roofline = None
-    if rank == 0 and not args.no_roofline:
-        # instrumented replay: HIP events around every conv_gemm launch of the acoustic model + vocoder (one stream)
-        from fastspeech2_amd import ops
-        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel", 5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)"}
+    res = {"dt": dt, "audio_s": audio_samples / 22050.0, "frames": float(frames), "n_batches": len(batches),
+           "first_batch": groups[0]}
+    if want_roofline:
+        # instrumented replay: HIP events around every conv_gemm launch of the acoustic model + vocoder (one stream), over
+        # every 8th batch of the pass
         ops.PROFILE = {}
-        for _ in range(2):
-            step()
+        nrep = 0
+        for i in range(0, len(batches), 8):
+            step(i)
+            nrep += 1
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         by = {}
@@ -265,26 +380,54 @@ def synth_main(args):
             peak = MFMA_PEAK_TFLOPS[args.vocoder_dtype]
             # the C = 32 / 64 residual-block convs (conv_skinny_kernel) are HBM-bound by construction (48-96 FLOP/B); every
             # other variant is priced against the MFMA peak
-            roofline = {"bound": "mfma", "kernel": names.get(dom, str(dom)) + " (%s)" % args.vocoder_dtype, "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
-                        "peak": peak, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
-                        "launches_per_step": n // 2, "kernel_ms_per_step": round(ms / 2, 3), "avg_launch_us": round(ms / n * 1e3, 1),
-                        "gflop_per_launch": round(fl / n / 1e9, 2),
-                        "conv_gemm_family": {v2: {"kernel": names.get(v2, str(v2)), "launches_per_step": d[2] // 2, "ms_per_step": round(d[1] / 2, 3),
-                                                  "tflops": round(d[0] / (d[1] * 1e-3) / 1e12, 1)} for v2, d in sorted(by.items())}}
+            res["roofline"] = {"bound": "mfma", "kernel": SYNTH_NAMES.get(dom, str(dom)) + " (%s)" % args.vocoder_dtype,
+                               "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                               "launches_per_step": round(n / nrep, 1), "kernel_ms_per_step": round(ms / nrep, 3),
+                               "avg_launch_us": round(ms / n * 1e3, 1), "gflop_per_launch": round(fl / n / 1e9, 2),
+                               "conv_gemm_family": {v2: {"kernel": SYNTH_NAMES.get(v2, str(v2)), "launches_per_step": round(d[2] / nrep, 1),
+                                                         "ms_per_step": round(d[1] / nrep, 3), "tflops": round(d[0] / (d[1] * 1e-3) / 1e12, 1)}
+                                                    for v2, d in sorted(by.items())},
+                               # HiFi-GAN: 614.1 MFLOP per mel frame
+                               "step_frac_of_peak": round(frames / dt * 614.1e6 / (peak * 1e12), 4)}
+    del model, voc, batches
+    return res
+
+
+def synth_workload_text(args):
+    return (f"BASELINE configs[4]: batch synthesis shaped like synthesize.py --mode batch over LJSpeech val.txt - 512 utterances in "
+            f"file order, {args.synth_batch} per batch (unsorted, padded per batch), real phoneme counts (13..132, mean 69.7), "
+            f"~7 frames/phoneme, 4+4 FastSpeech2 + HiFi-GAN V1, PCM copied to host")
+
+
+def synth_main(args):
+    lib_used = dev_environment()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    device = init_rank(world, local_rank)
+    r = synth_measure(args, device, rank, world, args.steps, args.warmup, rank == 0 and not args.no_roofline)
+    tt = torch.tensor([r["dt"], r["audio_s"], r["frames"]], device=device, dtype=torch.float64)
+    if world > 1:
+        tmax = tt[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt)
+        tt[0] = tmax[0]
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = synth_cpu_baseline(args, r["first_batch"], min(_thread_counts(args)[-1], 32))
     if rank == 0:
         dt, audio_s, frames = tt.tolist()
-        if roofline is not None:
-            roofline["step_frac_of_peak"] = round(frames / dt * 614.1e6 / (MFMA_PEAK_TFLOPS[args.vocoder_dtype] * 1e12), 4)   # HiFi-GAN: 614.1 MFLOP per mel frame
         print(json.dumps({
             "metric": "batch-synth real-time factor (acoustic model + HiFi-GAN + int16, 22.05 kHz)", "value": round(dt / audio_s, 6),
             "unit": "s wall per s audio", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": f"{args.dtype} acoustic / {args.vocoder_dtype} vocoder", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4]: batch synthesis, {B} utterances/batch, L<={args.phonemes} phonemes, "
-                                   f"~7 frames/phoneme, 4+4 FastSpeech2 + HiFi-GAN V1, PCM copied to host",
-                       "audio_s_per_step": round(audio_s / args.steps, 2), "mel_frames_per_s": round(frames / dt, 1),
+            "config": {"workload": synth_workload_text(args),
+                       "audio_s_per_step": round(audio_s / args.steps / world, 2), "mel_frames_per_s": round(frames / dt, 1),
                        "x_realtime": round(audio_s / dt, 1), "library": lib_used, "dev_env": []},
-            "roofline": roofline}))
+            "roofline": r.get("roofline"), "cpu_baseline": cpu}))
     if world > 1:
         dist.barrier()                     # ranks leave together (rank 0 was still replaying for the roofline)
         dist.destroy_process_group()
@@ -353,19 +496,15 @@ def main():
 
     use_graph = bool(args.graph) and world == 1
     graph = None
+    if use_graph:
+        model._engine.device_seed = True         # dropout position in device memory from the first warm-up step on
     for _ in range(max(args.warmup, 3) if use_graph else args.warmup):
         loss = step()
     torch.cuda.synchronize()
+    replay = None
     if use_graph:
         try:
-            # capture forward + loss + backward + clip/Adam; lr / bias corrections are read from device memory
-            graph = torch.cuda.CUDAGraph()
-            opt.zero_grad()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
-                static_loss = fwd_bwd()
-                opt.apply_update(zero_grad=True)
-            torch.cuda.synchronize()
+            graph, static_loss, replay = capture_graph(model, opt, fwd_bwd)
         except Exception as e:  # capture is an optimisation, never a change of what is computed
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graph = None
@@ -373,12 +512,7 @@ def main():
 
     def run_step():
         if graph is not None:
-            opt.current_step += 1
-            opt._adam_step += 1
-            lr = opt.init_lr * opt._get_lr_scale()
-            b1, b2 = opt.betas
-            opt.set_hyper(lr, 1 - b1 ** opt._adam_step, 1 - b2 ** opt._adam_step)
-            graph.replay()
+            replay()
         else:
             step()
 
@@ -427,6 +561,26 @@ def main():
                      "replicas_bit_identical": all(torch.equal(c, allchk[0]) for c in allchk)}
     value = frames.item() * args.steps / dt
     final_loss = float((static_loss if graph is not None else loss).item())
+    if world > 1:
+        # what each rank's OWN batch costs without the exchange (5 local steps; the replicas diverge from here on, nothing
+        # below depends on them): the data-parallel step runs at the slowest rank's pace
+        model._engine.grad_hook = None
+        loss_fn.count_reduce = None
+        local_step, _ = make_step(model, loss_fn, opt, b, None)
+        local_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            local_step()
+        torch.cuda.synchronize()
+        mine = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3, float(b["max_mel_len"]), float(b["max_src_len"]),
+                             float(b["mel_lens"].sum())], device=device, dtype=torch.float64)
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        ms = [float(x[0]) for x in allm]
+        dist_info.update({"per_rank_local_ms": [round(x, 3) for x in ms], "slowest_over_fastest": round(max(ms) / min(ms), 3),
+                          "per_rank_T": [int(x[1]) for x in allm], "per_rank_L": [int(x[2]) for x in allm],
+                          "per_rank_frames": [int(x[3]) for x in allm]})
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -434,16 +588,16 @@ def main():
         # (single stream for this replay: a kernel's event-bracketed duration is only its own when nothing runs beside it)
         side = model._engine.use_side_stream
         model._engine.use_side_stream = False
-        replay = step
+        prof_step = step
         if world > 1:
             # the other ranks are past the timed region: replay a LOCAL step (no gradient exchange, local loss counts) so that
             # rank 0 never enters a collective alone; kernel shapes and launches are the same
             model._engine.grad_hook = None
             loss_fn.count_reduce = None
-            replay, _ = make_step(model, loss_fn, opt, b, None)
+            prof_step, _ = make_step(model, loss_fn, opt, b, None)
         ops.PROFILE = {}
         for _ in range(3):
-            replay()
+            prof_step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         model._engine.use_side_stream = side
@@ -480,6 +634,18 @@ def main():
                                              for v2, d in sorted(by.items())},
                         "family_achieved": round(fam, 1), "family_frac": round(fam / peak, 4), "family_ms_per_step": round(tot_ms / 3, 3),
                         "step_frac_of_peak": round(value / world * train_flop_per_frame(args) / (peak * 1e12), 4)}
+            # the weight-gradient kernels of the same replay (side stream off: each duration is the kernel's own).  They run on
+            # the side stream in the timed step and are the largest block of device time after the contractions above.
+            wrec = prof.get("conv_wgrad", [])
+            if wrec:
+                wf, wms = sum(r[0] for r in wrec), sum(r[1].elapsed_time(r[2]) for r in wrec)
+                big = [r for r in wrec if r[3] > 1]
+                roofline["wgrad_family"] = {
+                    "launches_per_step": len(wrec) // 3, "ms_per_step": round(wms / 3, 3), "tflops": round(wf / (wms * 1e-3) / 1e12, 1),
+                    "frac": round(wf / (wms * 1e-3) / 1e12 / peak, 4),
+                    "taps_ge_3": {"launches_per_step": len(big) // 3,
+                                  "ms_per_step": round(sum(r[1].elapsed_time(r[2]) for r in big) / 3, 3),
+                                  "tflops": round(sum(r[0] for r in big) / max(sum(r[1].elapsed_time(r[2]) for r in big) * 1e-3, 1e-9) / 1e12, 1)}}
     # secondary figure: the same step in fp32 compute (the reference's own arithmetic; exact-f32 MFMA, 157.3 TF roof)
     fp32 = {}
     if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_fp32:
@@ -498,6 +664,19 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only (host cores are shared by the ranks)
         cpu = cpu_baseline(args)
+    synth = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_synth:
+        # the second half of BASELINE's metric rides on the driver's line: one warm-up pass + one timed pass over the
+        # val.txt-shaped batches (64 steps of 8 utterances), bf16 acoustic model + bf16 vocoder
+        r = synth_measure(args, device, 0, 1, 64, 64, not args.no_roofline)
+        synth = {"metric": "batch-synth real-time factor (acoustic model + HiFi-GAN + int16, 22.05 kHz)",
+                 "rtf": round(r["dt"] / r["audio_s"], 6), "unit": "s wall per s audio", "steps": 64, "warmup": 64,
+                 "ms_per_step": round(r["dt"] / 64 * 1e3, 3), "mel_frames_per_s": round(r["frames"] / r["dt"], 1),
+                 "x_realtime": round(r["audio_s"] / r["dt"], 1), "audio_s": round(r["audio_s"], 1),
+                 "dtype": f"{args.dtype} acoustic / {args.vocoder_dtype} vocoder", "workload": synth_workload_text(args),
+                 "roofline": r.get("roofline")}
+        if not args.no_cpu_baseline:
+            synth["cpu_baseline"] = synth_cpu_baseline(args, r["first_batch"], cpu["cores"] if cpu else min(_thread_counts(args)[-1], 32))
 
     if rank == 0:
         line = {
@@ -511,9 +690,9 @@ def main():
                                    "fwd+loss+bwd+clip+Adam, dropout on, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),
-                       "side_stream_wgrad": bool(model._engine.use_side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
+                       "side_stream_wgrad": bool(args.side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
                        "windows": len(window_s), "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in window_s],
-                       "library": lib_used, "dev_env": [], **fp32, **dist_info},
+                       "library": lib_used, "dev_env": [], **fp32, **dist_info, **({"synth": synth} if synth else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -43,9 +43,10 @@ def slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
     ramps = mel_f[:, None] - fft_f[None, :]
     lower = -ramps[:-2] / fdiff[:-1, None]
     upper = ramps[2:] / fdiff[1:, None]
-    w = np.maximum(0, np.minimum(lower, upper))
-    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
-    return w.astype(np.float32)
+    # rounding order of the float32 table librosa returns: triangles -> float32, x float64 area norm -> float32
+    w = np.maximum(0, np.minimum(lower, upper)).astype(np.float32)
+    w = (w.astype(np.float64) * (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]).astype(np.float32)
+    return w
 
 
 def dft_basis(filter_length, win_length):

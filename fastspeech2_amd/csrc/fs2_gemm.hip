@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "fs2_gemm.h"
+#include "fs2_sched.h"
 
 // final stage of the epilogue (shared by both GEMM kernels): the f32 tile staged in LDS is written out in whole
 // 16-byte row segments; residual / ReLU-gate operand and the accumulate operand are read the same way.
@@ -33,11 +34,7 @@
 // each read then touches 16 distinct quads, and a half-wave's ds_write_b32 of 32 consecutive floats still lands on 32 distinct
 // banks (positions distinct mod 8).  Checked exhaustively against the guide's lane groups on the host.  fp32 outputs (one
 // ds_read_b128 per lane, 16 bytes apart) are conflict-free in the natural layout and keep it.
-template <typename T> __host__ __device__ __forceinline__ int fs2_tile_col128(int c) {
-    if (sizeof(T) != 2) return c;
-    const int g = c >> 2, i = g >> 1;
-    return (((g & 1) ? 16 + ((i + 4) & 15) : i) << 2) | (c & 3);
-}
+template <typename T> __host__ __device__ __forceinline__ int fs2_tile_col128(int c) { return fs2_tile_col128_bytes((int)sizeof(T), c); }
 template <typename T, int TW = 128, int NT = 256, int ROWS = 128>
 __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const float* tile, int m0, int n0, int tid) {
     constexpr int EPC = MmaTraits<T>::EPC;
@@ -1063,13 +1060,6 @@ static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* b
     else conv_gemm_kernel<bf16_t><<<(unsigned)grid, 256, 0, stream>>>(a);
     FS2_CHECK_LAUNCH("conv_gemm");
     return FS2_OK;
-}
-
-// Test aid: column position of logical column c (0..127) inside a 128-float epilogue staging row for the given output dtype
-// (fs2_tile_col128).  tests/test_schedule_cpu.py checks the layout against the ds_read_b128 / ds_write_b32 service groups.
-extern "C" int fs2_stage_tile_col(int c, int dtype) {
-    FS2_CHECK_ARG(c >= 0 && c < 128 && (dtype == FS2_F32 || dtype == FS2_BF16), "stage_tile_col: bad arguments");
-    return dtype == FS2_BF16 ? fs2_tile_col128<bf16_t>(c) : fs2_tile_col128<float>(c);
 }
 
 extern "C" int fs2_conv_gemm(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,

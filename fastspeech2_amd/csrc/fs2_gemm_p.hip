@@ -40,6 +40,7 @@
 // releases the slot the consumers just left; LDS-DMA is issued from inline asm and tracked with counted vmcnt
 // (loaders), fragment reads with counted lgkmcnt (consumers) - see fs2_gemm.hip for why the compiler cannot do either.
 #include "fs2_gemm.h"
+#include "fs2_sched.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -73,78 +74,6 @@ static constexpr int P_MAXB = 1024;                       // lens[] staged in LD
 static constexpr int P_AUX_BYTES = P_MAXB * 4 + 4 * 512;  // lens + one 128-float bias line per consumer wave
 static constexpr int P_B_BYTES = 128 * 128;
 
-struct PSched {
-    int G, b;                  // workgroups in the launch, this workgroup
-    int ntm, ntn;              // M-tiles (real + padded), N-tiles
-    int n_real, n_pad;         // real / padded M-tiles (read from the tile map on the device)
-    const int32_t* tmap;       // [0] = n_real, [1 .. ntm] = real M-tiles then padded M-tiles; null = identity (no lens)
-    int ks, nkc_u;             // K-splits per output tile (1 = none) and Cin chunks per unit (= Cin/64/ks).  ks > 1: every unit
-                               // stores its partial 256x128 tile into its split's slab of the f32 workspace `ws` (ks x M x N) and
-                               // splitk_finalize_kernel sums the slabs into the bf16 output - for few-tile, long-reduction shapes
-                               // (the encoder's k=9 data gradient: 48 tiles x 144 K-steps on 256 CUs)
-    float* ws;
-    float* tws;                // tail slabs (one 256x128 f32 tile per workgroup) or null.  Non-null (and ks == 1): the LAST, partial
-    int tks_max;               // round of output tiles is K-split tks (<= tks_max, a power of two) ways so that it takes 1/tks of a
-                               // round instead of a whole one: 300 real tiles on 256 CUs ran as 2 rounds of 144 K-steps (the
-                               // k=9 data gradient), now 1 round + 44 tiles x 4 parts of 36 steps.  The parts store f32 partial
-                               // tiles into their workgroup's slab, p_tail_finalize_kernel sums them and applies the epilogue.
-    int order;                 // 0: M-fastest over all workgroups (neighbours share the weight slice);
-                               // 1: per XCD, N-fastest: the G/8 workgroups the dispatcher places on one XCD (b % 8) walk ALL
-                               //    N-tiles of the same M-tile together, so the activation tile is fetched into that XCD's L2
-                               //    once instead of once per N-tile (QKV re-read its input 6x from the Infinity Cache)
-};
-
-// Schedule of one workgroup GROUP (order 0: all G workgroups and all tiles; order 1: the G/8 workgroups of one XCD and the
-// tiles of the M-tiles mi = x mod 8): R full rounds, then `tail` tiles left over, each split `tks` ways (1 = not split).
-struct PPlan { int Gg, j, x, T, R, tail, tks; };
-__host__ __device__ __forceinline__ PPlan p_plan(const PSched& s, int b) {
-    PPlan p;
-    if (s.order == 0) { p.Gg = s.G; p.j = b; p.x = 0; p.T = s.n_real * s.ntn * s.ks; }
-    else {
-        p.x = b & 7; p.j = b >> 3; p.Gg = s.G >> 3;
-        const int nx = s.n_real > p.x ? (s.n_real - p.x + 7) >> 3 : 0;
-        p.T = nx * s.ntn * s.ks;
-    }
-    p.R = p.T / p.Gg;
-    p.tail = p.T - p.R * p.Gg;
-    p.tks = 1;
-    if (s.tws && p.tail > 0) {
-        int t = 1;
-        while (2 * t <= s.tks_max && 2 * t * p.tail <= p.Gg) t *= 2;
-        p.tks = t;
-    }
-    return p;
-}
-// position in the group's unit list -> (index into the real-M-tile list, N-tile, uniform K-split index)
-__host__ __device__ __forceinline__ void p_pos(const PSched& s, const PPlan& p, int pos, int& mi, int& nt, int& sp) {
-    if (s.order == 0) {
-        const int rest = pos / s.ks;
-        sp = pos - rest * s.ks;
-        nt = rest / s.n_real;
-        mi = rest - nt * s.n_real;
-    } else {
-        const int per = s.ntn * s.ks;
-        const int mil = pos / per, r = pos - mil * per;
-        nt = r / s.ks;
-        sp = r - nt * s.ks;
-        mi = p.x + 8 * mil;
-    }
-}
-// k-th unit of workgroup s.b: index into the real-M-tile list, N-tile, first Cin chunk and chunk count, tail part count (1 =
-// a whole tile); false when the workgroup has no k-th unit
-__host__ __device__ __forceinline__ bool p_unit(const PSched& s, int k, int& mi, int& nt, int& kc0, int& nkc, int& np) {
-    const PPlan p = p_plan(s, s.b);
-    int pos, part = 0;
-    np = 1;
-    if (k < p.R) pos = k * p.Gg + p.j;
-    else if (k == p.R && p.j < p.tail * p.tks) { pos = p.R * p.Gg + p.j / p.tks; part = p.j % p.tks; np = p.tks; }
-    else return false;
-    int sp;
-    p_pos(s, p, pos, mi, nt, sp);
-    nkc = s.nkc_u / np;
-    kc0 = sp * s.nkc_u + part * nkc;
-    return true;
-}
 __device__ __forceinline__ int p_ntiles(const PSched& s) {
     const PPlan p = p_plan(s, s.b);
     return p.R + (p.j < p.tail * p.tks ? 1 : 0);
@@ -863,27 +792,6 @@ static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream
     conv_gemm_p_kernel<ONE_TAP, WIDE, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
 }
 
-// The persistent kernel's schedule, evaluated on the HOST (the same p_plan / p_unit the device runs): the units of workgroup b of
-// a launch with n_real real M-tiles, ntn N-tiles, G workgroups, tile order `order`, uniform K-split ks over nkc Cin chunks and a
-// tail split of at most tks_max (1 = none).  out receives up to 64 x {mi, nt, kc0, nkc, parts}; returns the unit count.  Test aid
-// (tests/test_schedule_cpu.py proves every tile's chunk range is covered exactly once for any n_real).
-extern "C" int fs2_conv_gemm_p_units(int n_real, int ntn, int G, int order, int ks, int nkc, int tks_max, int b, int* out) {
-    FS2_CHECK_ARG(out && n_real >= 0 && ntn > 0 && G > 0 && ks > 0 && nkc > 0 && nkc % ks == 0 && b >= 0 && b < G && (order == 0 || G % 8 == 0),
-                  "conv_gemm_p_units: bad arguments");
-    PSched s = {};
-    s.G = G; s.b = b; s.ntm = n_real; s.ntn = ntn; s.n_real = n_real; s.n_pad = 0; s.tmap = nullptr;
-    s.ks = ks; s.nkc_u = nkc / ks; s.ws = nullptr; s.order = order;
-    s.tws = tks_max > 1 ? reinterpret_cast<float*>(16) : nullptr; s.tks_max = tks_max;
-    int n = 0;
-    for (int k = 0; k < 64; ++k) {
-        int mi, nt, kc0, nk, np;
-        if (!p_unit(s, k, mi, nt, kc0, nk, np)) break;
-        out[5 * n] = mi; out[5 * n + 1] = nt; out[5 * n + 2] = kc0; out[5 * n + 3] = nk; out[5 * n + 4] = np;
-        ++n;
-    }
-    return n;
-}
-
 // bytes of tail-split scratch fs2_conv_gemm_tail wants: one 256x128 f32 slab per workgroup of a full-chip launch
 extern "C" int fs2_conv_gemm_tail_ws_bytes(void) { return fs2_cu_count() * 256 * 128 * (int)sizeof(float); }
 
@@ -904,7 +812,12 @@ bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks) 
     const bool long_conv = taps >= 3 && (long)taps * (a.Cin >> 6) >= 96 && tiles >= cus / 8;
     if (tiles < (ks > 1 ? cus / 4 : cus / 2) && !long_conv) return false;
     const long G = tiles < cus ? tiles : cus;
-    if ((tiles + G - 1) / G > 64) return false;              // a workgroup's units travel in two VGPRs (lane k = k-th unit)
+    // a workgroup's units travel in two VGPRs (lane k = k-th unit, N-tile in 8 bits): at most 64 units per workgroup under
+    // EITHER tile order (per-XCD dealing gives group 0 up to ceil(ntm / 8) * ntn * ks tiles over G / 8 workgroups - one more
+    // round than the flat count near the boundary), at most 255 N-tiles; larger launches go to the ring kernel
+    const int ntm = fs2_cdiv(a.M, 256), ntn = fs2_cdiv(a.N, 128);
+    if (ntn > 255) return false;
+    if (p_max_units(ntm, ntn, ks, (int)G, 0) > 64 || (G % 8 == 0 && p_max_units(ntm, ntn, ks, (int)G, 1) > 64)) return false;
     return true;
 }
 

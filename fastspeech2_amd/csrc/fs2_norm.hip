@@ -327,7 +327,8 @@ __global__ void __launch_bounds__(512) ln_bwd_kernel(LnBwdArgs a) {
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(a.partial)[(size_t)FS2_LN_BWD_GRID * 2 * a.C] = (int)gridDim.x;
+    if (a.dgamma == nullptr && blockIdx.x == 0 && threadIdx.x == 0)      // deferred form only: the count fs2_ln_bwd_reduce reads (ws holds GRID*2*C + 4 floats then)
+        reinterpret_cast<int*>(a.partial)[(size_t)FS2_LN_BWD_GRID * 2 * a.C] = (int)gridDim.x;
     // block reduction of dgamma / dbeta partials: 4 waves -> LDS -> wave 0 -> partial[block][2][C]
     // (a second tiny kernel sums the per-block partials: no same-address atomic storm)
 #pragma unroll
@@ -437,7 +438,8 @@ __global__ void __launch_bounds__(512) ln_bwd_c256_bf16_kernel(LnBwdArgs a) {
             if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.d2) + (size_t)row * 256 + c) = pack8f(dz);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(a.partial)[(size_t)FS2_LN_BWD_GRID * 2 * 256] = (int)gridDim.x;
+    if (a.dgamma == nullptr && blockIdx.x == 0 && threadIdx.x == 0)      // deferred form only (see ln_bwd_kernel)
+        reinterpret_cast<int*>(a.partial)[(size_t)FS2_LN_BWD_GRID * 2 * 256] = (int)gridDim.x;
     // dgamma / dbeta partials of the workgroup: 16 half-waves -> LDS -> one column per thread -> partial[block][2][256]
     const int hw = w * 2 + hh;
     *reinterpret_cast<float4*>(&s_red[hw][c]) = make_float4(ag[0], ag[1], ag[2], ag[3]);
@@ -499,7 +501,12 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     a.seed_pre = seed_pre; a.seed_post = seed_post; a.seed_dev = seed_dev; a.relu_bwd = relu_bwd;
     FS2_CHECK_ARG(partial_ws, "ln_bwd: partial_ws (FS2_LN_BWD_GRID*2*C floats) is required");
     a.partial = partial_ws;
-    if (a.rows == 0) return FS2_OK;
+    if (a.rows == 0) {                                      // nothing to launch; the deferred reduce must still find a count (0 blocks)
+        if (!reduce_now && hipMemsetAsync(partial_ws + (size_t)FS2_LN_BWD_GRID * 2 * C, 0, sizeof(int), stream) != hipSuccess) {
+            fs2_set_error("ln_bwd: memset failed"); return FS2_ELAUNCH;
+        }
+        return FS2_OK;
+    }
     int grid = fs2_cdiv(a.rows, 8);
     if (grid > FS2_LN_BWD_GRID) grid = FS2_LN_BWD_GRID;
     const bool al16 = ((((uintptr_t)z | (uintptr_t)dout | (uintptr_t)d1_add | (uintptr_t)d1 | (uintptr_t)d2) & 15) == 0);

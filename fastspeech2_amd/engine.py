@@ -68,7 +68,6 @@ class Engine:
         self._ln_pending = []
         self.defer_ln_reduce = True
         self._pack_pending = False
-        self._tmaps = {}
         self._bn_ws = {}
         self._tail_ws = [None, None]
         self._on_side = False
@@ -241,9 +240,12 @@ class Engine:
             ws = self._bn_ws[C] = [z[0], z[1], z[2], 0]
         return ws
 
-    def _tmap(self, lens):
-        """tile map of a lengths tensor this forward registered (None otherwise: the non-persistent kernels run)."""
-        return self._tmaps.get(lens.data_ptr()) if lens is not None else None
+    @staticmethod
+    def _tmap(lens):
+        """tile map that ops.lens_prep made together with this lengths tensor (None otherwise: the non-persistent kernels run).
+        It travels ON the tensor object - the pair cannot be separated, outlive one another or be confused with another lengths
+        vector that happens to reuse the same device address (the round-2 version looked it up by data_ptr())."""
+        return getattr(lens, "_fs2_tmap", None) if lens is not None else None
 
     def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
         wf, _, b, shape = W[key]
@@ -496,8 +498,7 @@ class Engine:
         p_vp = self.vp["dropout"] if drop else 0.0
         p_pn = 0.5 if drop else 0.0
         st.counts = torch.empty(2, device=self.device, dtype=torch.float32)
-        src_lens32, st.src_masks, tmap_src = ops.lens_prep(st.src_lens, B, L, st.counts[0:1])
-        self._tmaps = {src_lens32.data_ptr(): tmap_src}
+        src_lens32, st.src_masks, src_lens32._fs2_tmap = ops.lens_prep(st.src_lens, B, L, st.counts[0:1])
 
         # ---- encoder (transformer/Models.py:73-100)
         n_head = self.tc["encoder_head"]
@@ -561,8 +562,7 @@ class Engine:
         Tdec = T if ((not training) and T > self.max_seq_len) else min(T, self.max_seq_len)
         cum, idx, mel_len = ops.lr_index(dur, Tdec)
         st.mel_lens_out, st.Tdec = mel_len, Tdec
-        dec_lens32, st.mel_masks, tmap_dec = ops.lens_prep(mel_len, B, Tdec, st.counts[1:2])
-        self._tmaps[dec_lens32.data_ptr()] = tmap_dec
+        dec_lens32, st.mel_masks, dec_lens32._fs2_tmap = ops.lens_prep(mel_len, B, Tdec, st.counts[1:2])
         frame_level = (not pitch_phone) or (not energy_phone)
         pe_dec = self._pe(P["decoder.position_enc"], Tdec)
         sv.x_lr_in = None
@@ -630,7 +630,6 @@ class Engine:
             sv.dec_out, sv.texts, sv.speakers = y, st.texts, st.speakers
             sv.pitch_phone, sv.energy_phone = pitch_phone, energy_phone
             sv.p_pn = p_pn
-            sv.tmaps = self._tmaps
         return (mel_o, post_o, p_pred, e_pred, logd), sv
 
     # ------------------------------------------------------------------ whole-model backward
@@ -645,7 +644,6 @@ class Engine:
             m._flat_grad.zero_()
             m.attach_grads()
         W, B, L, T, seed_dev = sv.W, sv.B, sv.L, sv.T, sv.seed_dev
-        self._tmaps = sv.tmaps
         n_mel = P["mel_linear.weight"].shape[0]
         self._side_begin()
 
@@ -682,12 +680,18 @@ class Engine:
 
         # ---- postnet backward
         g = dpost
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         for i in reversed(range(5)):
             pre = f"postnet.convolutions.{i}."
             s = sv.pn[i]
             ws = self._bn_workspace(s.c.shape[1])
             k = ws[3]
             ws[3] = 1 - k                               # ping-pong: this call reduces into ws[1+k] and clears ws[2-k] for the next one
+            if capturing:
+                # the parity above is HOST state: a captured step replays one fixed parity sequence, and a width with an odd
+                # number of BatchNorm layers (C = 80: one) would reduce into the same, never-cleared workspace on every replay.
+                # Inside a capture the target is cleared explicitly (a memset node; eager steps keep the launch-free ping-pong)
+                ws[1 + k].zero_()
             dc = ops.bn_bwd_acc(s.c, g, s.mean_rstd, P[pre + "1.weight"], P[pre + "1.bias"], s.act, sv.p_pn,
                                 _seed_pair(200 + i, seed_dev)[0], ws[1 + k], ws[2 - k], G[pre + "1.weight"], G[pre + "1.bias"],
                                 seed_dev=_seed_pair(200 + i, seed_dev)[1])

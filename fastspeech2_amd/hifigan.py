@@ -100,6 +100,7 @@ class Generator(nn.Module):
         self.conv_post = _WNConv((1, c0 // (2 ** self.num_upsamples), 7), c0 // (2 ** self.num_upsamples) * 7)
         self.set_compute_dtype(compute_dtype)
         self._packed = None
+        self.stage_probe = None          # a list: _run appends the output rows of conv_pre and of every up-sampling stage (tests)
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     def set_compute_dtype(self, compute_dtype):
@@ -174,6 +175,8 @@ class Generator(nn.Module):
         S = T
         wp, bp = W["pre"]
         x = ops.conv_gemm(x_rows, wp, bp, S, taps=7, pad=3)
+        if self.stage_probe is not None:
+            self.stage_probe.append((x, S))
         nk = self.num_kernels
         for i, u in enumerate(h["upsample_rates"]):
             wu, bu, taps, pad = W[f"up{i}"]
@@ -199,6 +202,8 @@ class Generator(nn.Module):
                         xs = ops.conv_gemm(t, w2, b2, S, taps=rk, pad=get_padding(rk, 1), res=cur, out=xs,
                                            accumulate=xs is not None, out_scale=1.0 / nk)
             x = xs
+            if self.stage_probe is not None:
+                self.stage_probe.append((x, S))
         wpost, bpost = W["post"]
         M = B * S
         wav = torch.empty(B, S, device=x.device, dtype=torch.float32) if want_wav else None

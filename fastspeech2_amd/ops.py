@@ -136,24 +136,6 @@ def tail_workspace(device):
     return torch.empty(_lib.load().fs2_conv_gemm_tail_ws_bytes() // 4, device=device, dtype=torch.float32)
 
 
-def splitk_for(M, N, Cin, taps, dtype):
-    """K-split depth the engine uses for a contraction: 1 unless the persistent kernel would run fewer than a quarter of the CUs'
-    worth of 256x128 tiles over a long reduction (>= 96 K-steps of 64) - the encoder's k=9 data gradient, 48 tiles x 144 steps.
-    Then the largest of 4 / 2 that divides the Cin chunks.  (r02f measured the first version - partial tiles ADDED into one
-    slab with row-per-lane float atomics - slower than not splitting: 100 us unsplit, 131 us at 2, 185 us at 4; the partial
-    tiles now go to per-split slabs with plain stores.)"""
-    if dtype != torch.bfloat16 or Cin % 64 or N % 8:
-        return 1
-    tiles = -(-M // TILE_ROWS) * -(-N // 128)
-    if tiles * 4 > CU_COUNT or taps * (Cin // 64) < 96:
-        return 1
-    for ks in (4, 2):
-        if (Cin // 64) % ks == 0 and tiles * ks <= CU_COUNT:
-            return ks
-    return 1
-
-
-CU_COUNT = 256       # MI355X
 TILE_ROWS = 256      # M-tile height of the persistent contraction kernel (fs2_gemm_p.hip)
 
 
@@ -181,8 +163,14 @@ def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None, dbias=None):
     """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x;  dbias (Cout,) fp32 += column sums of dy (same pass)."""
     M, N = dy.shape
     Cin = x.shape[1]
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("fs2_conv_wgrad", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(dbias), _p(lens), M, N, Cin, S, taps, dil,
               pad, dt(dy), _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.setdefault("conv_wgrad", []).append((2.0 * M * N * Cin * taps, e0, e1, taps, lens is not None, S))
 
 
 def colsum(x, out):

@@ -40,6 +40,13 @@ PREPROCESS = {
     },
 }
 
+def val_phoneme_counts():
+    """phoneme count of every line of the reference's preprocessed_data/LJSpeech/val.txt, in file order (512 utterances;
+    table made by tools/make_val_shape.py from the reference, committed under fastspeech2_amd/workloads/)."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "workloads", "ljspeech_val_phonemes.json")) as f:
+        return json.load(f)["counts"]
+
+
 TRAIN = {
     "path": {"ckpt_path": "./output/ckpt/LJSpeech", "log_path": "./output/log/LJSpeech", "result_path": "./output/result/LJSpeech"},
     "optimizer": {"batch_size": 48, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0, "grad_clip_thresh": 1.0,
@@ -89,14 +96,20 @@ def make_configs(dec_layers=4, multi_speaker=False, frame_level=False, dropout=T
 
 
 def synthetic_batch(seed, B, L, dur_lo=2, dur_hi=8, n_mel=80, n_vocab=361, n_speaker=1, min_len_frac=0.6,
-                    max_seq_len=1000, frame_level=False):
+                    max_seq_len=1000, frame_level=False, src_lens=None, sort=True):
     """LJSpeech-shaped synthetic batch: the reference's 12-tuple minus ids/raw_texts.
-    Returns dict of CPU tensors + python ints."""
+    Returns dict of CPU tensors + python ints.  src_lens (optional): the utterances' phoneme counts (then B = len(src_lens),
+    L = their maximum; `sort` = False keeps their order, as a TextDataset batch does)."""
     g = torch.Generator().manual_seed(seed)
-    lo = max(1, int(L * min_len_frac))
-    src_lens = torch.randint(lo, L + 1, (B,), generator=g)
-    src_lens[0] = L
-    src_lens, _ = torch.sort(src_lens, descending=True)
+    if src_lens is not None:
+        src_lens = torch.as_tensor(src_lens, dtype=torch.int64).clone()
+        B, L = int(src_lens.numel()), int(src_lens.max())
+    else:
+        lo = max(1, int(L * min_len_frac))
+        src_lens = torch.randint(lo, L + 1, (B,), generator=g)
+        src_lens[0] = L
+    if sort:
+        src_lens, _ = torch.sort(src_lens, descending=True)
     texts = torch.randint(1, n_vocab, (B, L), generator=g)
     durations = torch.randint(dur_lo, dur_hi + 1, (B, L), generator=g)
     valid = torch.arange(L).unsqueeze(0) < src_lens.unsqueeze(1)

@@ -27,10 +27,8 @@ def get_model(args, configs, device, train=False, compute_dtype=None):
     ckpt = None
     if args.restore_step:
         ckpt_path = os.path.join(train_config["path"]["ckpt_path"], "{}.pth.tar".format(args.restore_step))
-        # checkpoints written by the reference hold a numpy scalar (param_groups[0]["lr"]: init_lr is np.power(...),
-        # model/optimizer.py:19,50) which torch >= 2.6's default weights_only unpickler rejects; they are the user's own
-        # training artefacts, loaded the way the reference loads them (utils/model.py:20)
-        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        # (checkpoints written by the reference hold a numpy scalar learning rate: see load_checkpoint)
+        ckpt = load_checkpoint(ckpt_path)
         model.load_state_dict(ckpt["model"])
         model._dropout_step = int(args.restore_step)      # dropout masks continue their sequence instead of replaying it
     if train:
@@ -42,6 +40,23 @@ def get_model(args, configs, device, train=False, compute_dtype=None):
     model.eval()
     model.requires_grad_ = False                 # attribute assignment in the reference too (utils/model.py:33)
     return model
+
+
+def load_checkpoint(path):
+    """torch.load with the SAFE (weights_only) unpickler.  Checkpoints written by the reference hold one non-tensor object, a
+    numpy scalar (param_groups[0]["lr"]: init_lr is np.power(...), model/optimizer.py:19,50), which torch >= 2.6's default
+    unpickler rejects; exactly the numpy scalar reconstruction globals are allow-listed for the call instead of switching the
+    safe unpickler off."""
+    import numpy as _np
+    allow = [_np.dtype, _np.ndarray]
+    try:
+        from numpy._core import multiarray as _ma      # numpy >= 2 (pickles written by numpy 1.x name numpy.core.multiarray,
+    except ImportError:                                 # which numpy 2 resolves to the same objects)
+        from numpy.core import multiarray as _ma
+    allow += [_ma.scalar, _ma._reconstruct]
+    allow += [type(_np.dtype(t)) for t in ("float64", "float32", "int64", "int32")]
+    with torch.serialization.safe_globals(allow):
+        return torch.load(path, map_location="cpu", weights_only=True)
 
 
 def get_param_num(model):
@@ -64,7 +79,8 @@ def get_vocoder(config, device, hifigan_dir="hifigan", compute_dtype="fp32", all
     ckpt_path = os.path.join(hifigan_dir, {"LJSpeech": "generator_LJSpeech.pth.tar",
                                            "universal": "generator_universal.pth.tar"}[speaker])
     if os.path.exists(ckpt_path):
-        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        # a third-party download holding plain tensors: the safe unpickler, always
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
         vocoder.load_state_dict(ckpt["generator"])
     elif not allow_random_init:
         raise FileNotFoundError(ckpt_path)

@@ -67,14 +67,6 @@ int fs2_conv_gemm_tail(const void* X, long ldx, const void* Wpacked, const float
                        long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin, int S,
                        int taps, int dil, int pad, int act, float slope, int in_act, float in_slope, int accumulate,
                        float out_scale, int dtype, fs2_stream_t stream);
-/* Test aid: position of logical column c (0..127) in a 128-float epilogue staging row of the 128x128 / ring / skinny kernels for
- * output dtype FS2_F32 / FS2_BF16 (a position, not a status; negative on bad arguments). */
-int fs2_stage_tile_col(int c, int dtype);
-/* Test aid: the persistent kernel's unit list of workgroup b, evaluated on the host by the same schedule functions the device
- * runs (n_real real M-tiles, ntn N-tiles, G workgroups, tile order 0 / 1, uniform K-split ks over nkc Cin chunks, tail split of
- * at most tks_max, 1 = none).  out: up to 64 x {real-tile index, N-tile, first chunk, chunk count, tail parts}.  Returns the unit
- * count (a count, not a status); negative on bad arguments. */
-int fs2_conv_gemm_p_units(int n_real, int ntn, int G, int order, int ks, int nkc, int tks_max, int b, int* out);
 /* K-split form for few-tile, long-reduction contractions: `ksplit` workgroups per output tile store partial tiles into ws
  * (f32 scratch, ksplit x M x N, any contents), one more launch sums them and finalises (bias, activation, residual, bf16).
  * bf16 only, Cin % (64 ksplit) == 0; FS2_EINVAL for unsupported shapes (fall back to fs2_conv_gemm). */
@@ -123,9 +115,10 @@ int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, 
                float* mean, float* rstd, int B, int S, int C, float eps, float p_pre, uint64_t seed_pre, float p_post,
                uint64_t seed_post, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 /* d1 = dz (+ d1_add), d2 = dz * dropmask_pre * (relu_bwd ? z>0 : 1); dgamma/dbeta += column sums.
- * partial_ws: caller workspace of FS2_LN_BWD_GRID*2*C + 4 floats (per-block partial sums and their count, reduced by a 2nd
- * launch).  dgamma = dbeta = NULL defers that launch: call fs2_ln_bwd_reduce(partial_ws, ...) later, on any stream ordered
- * after this call, before partial_ws is reused. */
+ * partial_ws: caller workspace of per-block partial sums, reduced by a 2nd launch: FS2_LN_BWD_GRID*2*C floats when dgamma /
+ * dbeta are given (nothing is written beyond that).  dgamma = dbeta = NULL DEFERS the reduction: the workspace must then hold
+ * FS2_LN_BWD_GRID*2*C + 4 floats (the block count is stored behind the partials) and the caller runs
+ * fs2_ln_bwd_reduce(partial_ws, ...) later, on any stream ordered after this call, before partial_ws is reused. */
 #define FS2_LN_BWD_GRID 1024
 int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
                const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,

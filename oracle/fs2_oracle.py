@@ -282,6 +282,57 @@ def hifigan_forward(sd, h, mel):
     return torch.tanh(x)
 
 
+def bf16_store(t):
+    """round to bfloat16 (nearest even) and back: what a product tensor STORED in bf16 holds."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def hifigan_forward_stored(sd, h, mel, store=None, stages=None, stage_inputs=None, weight_store=None):
+    """hifigan_forward with the PRODUCT's storage points made explicit (fastspeech2_amd/hifigan.py `_run`): `store` is applied
+    wherever the product writes an activation to HBM in its compute dtype - the mel rows, every convolution's output (after
+    the fused leaky-ReLU / residual / `xs / 3` accumulate epilogue) and the leaky-ReLU'd operand of the pre-activation
+    convolutions (the LDS-DMA prologue re-rounds it) - and `weight_store` to the packed weights (conv_post's stay fp32).
+    With store = weight_store = None this is hifigan_forward up to summation order (tests/test_oracle_golden.py); with
+    bf16_store it is the bf16 EMULATION the bf16 bars are derived from (the product differs from it by accumulation order only).
+    stages: list that receives the output of conv_pre and of every up-sampling stage; stage_inputs: tensors to use as the INPUT
+    of stage i instead (i = 0: conv_pre <- mel ... len-1: conv_post) - per-stage comparisons that do not compound."""
+    st = store if store is not None else (lambda t: t)
+    wst = weight_store if weight_store is not None else (lambda t: t)
+
+    def inp(i, x):
+        return stage_inputs[i] if (stage_inputs is not None and stage_inputs[i] is not None) else x
+
+    x = F.conv1d(st(inp(0, mel)), wst(sd["conv_pre.weight"]), sd["conv_pre.bias"], padding=3)
+    x = st(x)
+    if stages is not None:
+        stages.append(x)
+    nk = len(h["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        x = inp(1 + i, x)
+        x = F.conv_transpose1d(st(F.leaky_relu(x, 0.1)), wst(sd[f"ups.{i}.weight"]), sd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+        x = st(x)
+        xs = None
+        for j, (rk, rd) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+            pre = f"resblocks.{i * nk + j}."
+            y = x
+            for m, d in enumerate(rd):
+                t = F.conv1d(st(F.leaky_relu(y, 0.1)), wst(sd[f"{pre}convs1.{m}.weight"]), sd[f"{pre}convs1.{m}.bias"], dilation=d,
+                             padding=(rk * d - d) // 2)
+                t = st(F.leaky_relu(t, 0.1))
+                t = F.conv1d(t, wst(sd[f"{pre}convs2.{m}.weight"]), sd[f"{pre}convs2.{m}.bias"], padding=(rk - 1) // 2) + y
+                if m < len(rd) - 1:
+                    y = st(t)
+                else:                                   # last conv of the branch: xs (+)= (conv + y) / nk, stored each time
+                    xs = st(t / nk) if xs is None else st(xs + t / nk)
+        x = xs
+        if stages is not None:
+            stages.append(x)
+    x = inp(1 + len(h["upsample_rates"]), x)
+    x = F.leaky_relu(x)
+    x = F.conv1d(x, sd["conv_post.weight"], sd["conv_post.bias"], padding=3)
+    return torch.tanh(x)
+
+
 def remove_weight_norm_sd(sd):
     """weight_g / weight_v -> weight = g * v / ||v|| (norm over all dims but 0), as torch.nn.utils.weight_norm."""
     out = {}
@@ -333,14 +384,17 @@ def slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
     mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
     fdiff = np.diff(mel_f)
     ramps = np.subtract.outer(mel_f, fftfreqs)
-    weights = np.zeros((n_mels, n_freq))
+    # librosa builds the table in its OUTPUT dtype (float32): the float64 triangles are rounded to float32 when they are
+    # assigned, the area normalisation then multiplies the float32 table by the float64 `enorm` (numpy computes float32 *
+    # float64 in float64) and the in-place result is rounded to float32 again - two roundings, reproduced here in that order
+    weights = np.zeros((n_mels, n_freq), dtype=np.float32)
     for i in range(n_mels):
         lower = -ramps[i] / fdiff[i]
         upper = ramps[i + 2] / fdiff[i + 1]
         weights[i] = np.maximum(0, np.minimum(lower, upper))
     enorm = 2.0 / (mel_f[2 : n_mels + 2] - mel_f[:n_mels])
     weights *= enorm[:, None]
-    return weights.astype(np.float32)
+    return weights
 
 
 def stft_basis(filter_length, win_length):

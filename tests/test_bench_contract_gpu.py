@@ -42,7 +42,21 @@ def test_bench_line_contract(dev):
     assert cfg["fp32_ms_per_step"] > d["ms_per_step"] and 0.05 < cfg["fp32_frac_of_f32_peak"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "mel-frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert "median of 8" in c["sample"] and "2 discarded" in c["sample"] and f"{c['cores']} torch threads" in c["sample"]
+    assert c["cores"] <= 64                                                # swept, never every logical CPU of the box
     assert d["value"] > 100 * c["value"]
+    # the weight-gradient family is in the line (it was invisible next to the "dominant" kernel)
+    w = r["wgrad_family"]
+    assert w["launches_per_step"] >= 40 and w["ms_per_step"] > 0 and abs(w["frac"] - w["tflops"] / r["peak"]) < 1e-3
+    assert 0 < w["taps_ge_3"]["ms_per_step"] <= w["ms_per_step"]
+    # the second half of BASELINE's metric rides on the driver's line: batch-synthesis RTF on the val.txt-shaped workload
+    sy = cfg["synth"]
+    assert 0 < sy["rtf"] < 0.01 and sy["steps"] == 64 and "val.txt" in sy["workload"] and sy["mel_frames_per_s"] > 1e4
+    assert abs(sy["rtf"] * sy["x_realtime"] - 1.0) < 0.02
+    sr = sy["roofline"]
+    assert sr["bound"] == "mfma" and 0 < sr["frac"] < 1 and abs(sr["frac"] - sr["achieved"] / sr["peak"]) < 1e-3
+    sc = sy["cpu_baseline"]
+    assert sc["kind"] == "port" and sc["value"] > 10 * sy["rtf"] and sc["cores"] >= 1
 
 
 def test_bench_refuses_development_switches(dev):
@@ -53,11 +67,11 @@ def test_bench_refuses_development_switches(dev):
 
 
 def test_bench_synth_line_has_roofline(dev):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "synth", "--steps", "2", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "synth", "--steps", "16", "--warmup", "16",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][0])
-    assert d["higher_is_better"] is False and d["value"] > 0
+    assert d["higher_is_better"] is False and d["value"] > 0 and d["steps"] == 16 and "val.txt" in d["config"]["workload"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["kernel"].startswith("conv_") and r["launches_per_step"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -82,3 +96,23 @@ def test_bench_two_ranks_shared_gpu(dev):
     assert 2 * 0.75 * 48 * 925 < frames_per_step <= 2 * 48 * 925 * 1.001, frames_per_step
     assert d["roofline"]["kernel"].startswith("conv_gemm_p_kernel<false>") and d["roofline"]["launches_per_step"] >= 16
     assert d["cpu_baseline"] is None                                        # reported at N=1 only
+    assert "synth" not in d["config"]                                       # (replicas only; reported at N=1)
+    ms = d["config"]["per_rank_local_ms"]
+    assert len(ms) == 2 and min(ms) > 0 and abs(d["config"]["slowest_over_fastest"] - max(ms) / min(ms)) < 1e-2
+
+
+def test_bench_two_ranks_libritts_buckets_differ(dev):
+    """config 4's shape: every rank takes ITS OWN bucket of one step from the real length-bucketed sampler; the line carries the
+    per-rank shapes and local step times."""
+    env = dict(os.environ, FS2_BENCH_BACKEND="gloo", FS2_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "libritts",
+           "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][0])
+    c = d["config"]
+    assert c["replicas_bit_identical"] is True and len(c["per_rank_T"]) == 2 and len(c["per_rank_frames"]) == 2
+    assert c["per_rank_frames"][0] != c["per_rank_frames"][1]              # different buckets ...
+    assert abs(c["per_rank_L"][0] - c["per_rank_L"][1]) <= 0.2 * max(c["per_rank_L"])   # ... of the same length class (card-wise deal)
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - sum(c["per_rank_frames"])) <= 1e-3 * sum(c["per_rank_frames"])

@@ -113,6 +113,27 @@ def hifigan_weights(seed, keys, gain=1.2):
     return new
 
 
+def test_hifigan_stored_oracle_is_the_oracle_when_nothing_is_rounded():
+    """oracle.hifigan_forward_stored (the product's storage points made explicit: the form the bf16 bars are derived from) with
+    no rounding equals hifigan_forward (pinned by the reference golden) up to fp64 summation order; the stage probes and the
+    per-stage input substitution are consistent; with bf16 storage it moves by a bf16-sized amount."""
+    keys = sorted(hifigan_shapes().keys())
+    sd = O.remove_weight_norm_sd({k: v.double() for k, v in hifigan_weights(5, keys).items()})
+    mel = torch.clamp(torch.randn(2, 80, 9, generator=torch.Generator().manual_seed(3)) * 2 - 5, -11.5, 2.0).double()
+    with torch.no_grad():
+        ref = O.hifigan_forward(sd, configs.HIFIGAN, mel)
+        stages = []
+        got = O.hifigan_forward_stored(sd, configs.HIFIGAN, mel, stages=stages)
+        assert (got - ref).abs().max().item() < 1e-12 and len(stages) == 5
+        assert [tuple(t.shape[1:]) for t in stages] == [(512, 9), (256, 72), (128, 576), (64, 1152), (32, 2304)]
+        # feeding every stage its own recorded input reproduces the run
+        again = O.hifigan_forward_stored(sd, configs.HIFIGAN, mel, stage_inputs=[None] + stages)
+        assert (again - got).abs().max().item() < 1e-12
+        emu = O.hifigan_forward_stored(sd, configs.HIFIGAN, mel, store=O.bf16_store, weight_store=O.bf16_store)
+    rel = float((emu - ref).norm() / ref.norm())
+    assert 1e-4 < rel < 5e-2, rel
+
+
 def hifigan_shapes(h=configs.HIFIGAN):
     """state_dict schema of hifigan.Generator (reference hifigan/models.py:113-147) with weight-norm keys."""
     s = {}
