@@ -176,6 +176,11 @@ def capture_graph(model, opt, fwd_bwd):
     kernel arguments.  BatchNorm's backward workspaces are cleared inside the capture (engine.py), so replays do not
     accumulate into each other."""
     assert model._engine.device_seed, "set model._engine.device_seed = True before warm-up and capture"
+    # ONE stream inside the capture: with the weight-gradient / variance-predictor branches forked onto the side stream inside a
+    # capture, replays came out with gradients 2.8e-3 (relative, Adam first moments after 4 replays) away from the eager steps
+    # (tests/test_graph_gpu.py, round 3; single-stream capture matches to 1e-6), and the forked capture was also the slowest
+    # variant (DESIGN §3: 16.9 ms vs 11.6 single-stream vs 9.3 eager with the side stream) - so the graph path does not fork.
+    model._engine.use_side_stream = False
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad()
     torch.cuda.synchronize()
@@ -690,7 +695,7 @@ def main():
                                    "fwd+loss+bwd+clip+Adam, dropout on, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),
-                       "side_stream_wgrad": bool(args.side_stream), **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
+                       "side_stream_wgrad": bool(args.side_stream) and graph is None, **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
                        "windows": len(window_s), "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in window_s],
                        "library": lib_used, "dev_env": [], **fp32, **dist_info, **({"synth": synth} if synth else {})},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -24,6 +24,7 @@
 
 #include "fs2_gemm.h"
 #include "fs2_sched.h"
+#include "fs2_wgrad.h"
 
 // final stage of the epilogue (shared by both GEMM kernels): the f32 tile staged in LDS is written out in whole
 // 16-byte row segments; residual / ReLU-gate operand and the accumulate operand are read the same way.
@@ -1184,14 +1185,6 @@ extern "C" int fs2_pack_dgrad_multi(const float* flat, void* wd_base, const int6
 //      v_mfma_f32_32x32x2_f32.
 // bf16 inputs are widened to f32 when staged (first version; a bf16-MFMA wgrad with transposing
 // LDS reads replaces this in a later revision).
-struct WgradArgs {
-    const void* dY; long lddy;
-    const void* X; long ldx;
-    float* dW;
-    float* dbias;          // optional: dbias[n] += sum_m dY[m][n], fused into the blocks that own (c-tile 0, tap group 0)
-    const int32_t* lens;   // optional: dY rows t >= lens[seq] are known to be zero -> their K-tiles are skipped
-    int M, N, Cin, S, taps, dil, pad, rows_per_split, g3, dbg;
-};
 
 template <typename T>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
@@ -1509,6 +1502,11 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
     }
     if (FS2_DEV_DBG(a.dbg & 1)) return;
     const int fl = lane & 31, fh = lane >> 5;
+    // split-K: with a slab, this split's partial tile goes to its OWN copy of dW (plain stores, a half-wave writes 32 consecutive
+    // c = one full 128-byte line per store) and wgrad_finalize_kernel sums the splits in a fixed order (bit-reproducible
+    // gradients); without one, fp32 atomics straight into the master gradient (round-1/2 path: a full-tile burst of ~2 TB/s
+    // device-scope atomics per split - the ~80 us tail of the k=9 launch)
+    float* const outW = a.slab ? a.slab + (size_t)blockIdx.y * a.slab_stride : a.dW;
     if (do_bias) {                                       // reduce the 16 row-threads of every column group through LDS
         float* red = reinterpret_cast<float*>(smem);     // [16][128]; the operand tiles are dead (last loop barrier passed)
 #pragma unroll
@@ -1518,7 +1516,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < RS; ++r) t += red[r * 128 + tid];
-            atomicAdd(a.dbias + n0 + tid, t);
+            if (a.slab) outW[(size_t)a.N * a.taps * a.Cin + n0 + tid] = t;
+            else atomicAdd(a.dbias + n0 + tid, t);
         }
     }
 #pragma unroll
@@ -1531,10 +1530,38 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, unsigned cha
             for (int r = 0; r < 16; ++r) {
                 int n = n0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n >= a.N) continue;
-                float* dst = a.dW + ((size_t)n * a.taps + tap0) * a.Cin + c;
+                float* dst = outW + ((size_t)n * a.taps + tap0) * a.Cin + c;
+                if (a.slab) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) atomicAdd(dst + (size_t)t * a.Cin, acc[t][mb][nb][r]);
+                    for (int t = 0; t < NT; ++t) dst[(size_t)t * a.Cin] = acc[t][mb][nb][r];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) atomicAdd(dst + (size_t)t * a.Cin, acc[t][mb][nb][r]);
+                }
             }
+    }
+}
+
+// dW[i] += sum_s slab[s][i] over the nw = N*taps*Cin weight entries; dbias[n] += sum_s slab[s][nw + n] (splits in index order: the
+// result does not depend on which workgroup finished first).  One thread = 4 consecutive floats.
+__global__ void __launch_bounds__(256) wgrad_finalize_kernel(float* __restrict__ dW, float* __restrict__ dbias, const float* __restrict__ slab,
+                                                             long slab_stride, int nsplit, long nw, int N) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i < nw) {
+        float4 v = *reinterpret_cast<const float4*>(dW + i);
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float4 x = *reinterpret_cast<const float4*>(slab + (size_t)sp * slab_stride + i);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        *reinterpret_cast<float4*>(dW + i) = v;
+    } else if (dbias && i - nw < N) {                    // (nw % 4 == 0, N % 4 == 0)
+        const long n = i - nw;
+        float4 v = *reinterpret_cast<const float4*>(dbias + n);
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float4 x = *reinterpret_cast<const float4*>(slab + (size_t)sp * slab_stride + nw + n);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        *reinterpret_cast<float4*>(dbias + n) = v;
     }
 }
 
@@ -1551,8 +1578,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) conv_wgrad_bf16_kern
     else wgrad_bf16_body<(REM ? REM : 1), NW>(a, smem, tile_n, tile_c, a.g3 * NT);
 }
 
+extern "C" int fs2_conv_wgrad_ws_bytes(int M, int N, int Cin, int S, int taps, int dil, int has_lens, int dtype) {
+    if (dtype != FS2_BF16 || M <= 0 || N <= 0 || Cin <= 0 || S <= 0 || taps <= 0) return 0;
+    const WgradPlan p = wgrad_plan(M, N, Cin, S, taps, dil, has_lens != 0, true);
+    const long b = (long)p.splits * ((long)N * taps * Cin + N) * 4;
+    return b > 0x7fffffffL ? 0 : (int)b;                 // (a single slab beyond 2 GB: no workspace -> the atomic path)
+}
+
 template <int NT, int REM, int NW>
-static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream) {
+static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream, const WgradPlan* plan = nullptr) {
     a.S = S_eff;
     a.g3 = g3;
     static const int dbg = fs2_dev_env("FS2_WGRAD_DBG", 0);
@@ -1564,22 +1598,21 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
     long tiles = (long)fs2_cdiv(a.N, 128) * fs2_cdiv(a.Cin, 128) * groups;
     int tps = (a.S + 63) / 64;
     long units = (long)(a.M / a.S) * tps;
-    // Split-K depth.  Every split ends with a full-tile burst of fp32 atomics (~2 TB/s, all CUs at once) and every
+    if (plan) {                                           // slab split-K: depth from wgrad_plan (the workspace was sized by it)
+        a.rows_per_split = plan->ups;
+        dim3 grid((unsigned)tiles, (unsigned)plan->splits);
+        conv_wgrad_bf16_kernel<NT, REM, NW><<<grid, 64 * NW, dyn, stream>>>(a);
+        return;
+    }
+    // Split-K depth (ATOMIC path).  Every split ends with a full-tile burst of fp32 atomics (~2 TB/s, all CUs at once) and every
     // workgroup pays ~10 us of prologue/epilogue, so the depth is bounded from both sides (r01h sweep, tools/bench_wgrad.py):
     //   short reductions (encoder, 96 K-tiles)  -> ~192 workgroups;  1-tap GEMMs (2 workgroups per CU) -> ~384;  else ~768;
     //   and at least 8 (1-tap) / 16 (few-tile conv) K-tiles per workgroup when the reduction is long.
     static const int wg_env = fs2_dev_env("FS2_WGRAD_WGS", 0);
     static const int ups_env = fs2_dev_env("FS2_WGRAD_MINUPS", 0);
-    // 8-wave tap-group kernels (one workgroup per CU): ONE round of <= 256 workgroups.  With two waves per SIMD a workgroup
-    // no longer needs a successor queued behind it to hide its latencies, and every extra split is another full-tile burst
-    // of atomics (r01k sweep: k=9 FFN 294 -> 250 us at 5 splits x 48 tiles, PostNet k=5 201 -> 158 us at 8 x 32).
     // r02 same-box A/B of the WHOLE step (tools/ab_env.py): these launches run on the side stream next to the data-gradient
-    // chain, and fewer, longer workgroups disturb it less than the split depth that is fastest in isolation (one-tap 384 ->
-    // 192, tap-group kernels 256 -> 128 workgroups: 10.16 -> 9.90 ms per step; 96 and below lose again).  Re-tuned at the end of
-    // round 2, after the variance predictors and the LayerNorm reductions moved to the side stream and the attention kernels got
-    // shorter: tap-group kernels at 192 (k=9 FFN 4 splits x 48 tiles, PostNet k=5 6 x 32) instead of 128 (2 / 4 splits):
-    // 9.75 -> 9.25 ms and 9.3 -> 9.05 ms on two boxes; 160 ... 224 are within 0.3 %, 240+ (5 splits of the k=9 FFN) and 96
-    // lose 2 % (profiles/r02y_ab_env*.log)
+    // chain, and fewer, longer workgroups disturb it less than the split depth that is fastest in isolation: tap-group kernels
+    // at 192 workgroups, one-tap at 192 (profiles/r02y_ab_env*.log)
     int wg_target = units < 256 ? 192 : (NT == 1 ? 192 : (NW == 8 ? 192 : 768));
     int min_ups = NT == 1 ? 8 : ((tiles <= 8 && units >= 512) ? 16 : 4);
     if (wg_env) wg_target = wg_env;
@@ -1598,15 +1631,16 @@ static void launch_wgrad_bf16(WgradArgs a, int S_eff, int g3, hipStream_t stream
 
 extern "C" int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, hipStream_t stream);
 
-extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens,
-                              int M, int N, int Cin, int S, int taps, int dil, int pad, int dtype, hipStream_t stream) {
+static int conv_wgrad_impl(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens,
+                           int M, int N, int Cin, int S, int taps, int dil, int pad, int dtype, float* ws, long ws_bytes,
+                           hipStream_t stream) {
     FS2_CHECK_ARG(dY && X && dW, "conv_wgrad: null pointer");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0, "conv_wgrad: bad shape");
     FS2_CHECK_ARG(N % 4 == 0 && Cin % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0, "conv_wgrad: N/Cin/ld must be multiples of 4");
     if (M == 0) return FS2_OK;
     WgradArgs a;
     a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.dW = dW; a.dbias = dbias; a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps;
-    a.dil = dil; a.pad = pad; a.g3 = 0; a.dbg = 0;
+    a.dil = dil; a.pad = pad; a.g3 = 0; a.dbg = 0; a.slab = nullptr; a.slab_stride = 0;
     long tiles = (long)fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128) * taps;
     // split rows so that ~1024 workgroups exist, each covering a multiple of 32 rows (>= 256 rows).
     long want = (1024 + tiles - 1) / tiles;
@@ -1622,29 +1656,67 @@ extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx
         bool fast = (N % 8 == 0) && (Cin % 8 == 0) && (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0;
         static const int wg_waves = fs2_dev_env("FS2_WGRAD_WAVES", 8);   // dev A/B: 4 | 8
         static const int wg_waves1 = fs2_dev_env("FS2_WGRAD_WAVES1", 4);            // dev A/B: 4 | 8
-        if (fast && taps == 1) {
-            if (wg_waves1 == 8) launch_wgrad_bf16<1, 0, 8>(a, (lens && M % S == 0) ? S : M, 1, stream);
-            else launch_wgrad_bf16<1, 0, 4>(a, (lens && M % S == 0) ? S : M, 1, stream);
+        const bool conv_ok = fast && taps > 1 && 2 * dil <= 8 && M % S == 0;
+        const bool one_ok = fast && taps == 1;
+        // slab split-K (round 3): needs the caller's workspace (fs2_conv_wgrad_ws_bytes) and 16-byte addressable gradients
+        static const int slab_env = fs2_dev_env("FS2_WGRAD_SLAB", 1);   // dev A/B: 0 = atomics even with a workspace
+        WgradPlan plan = wgrad_plan(M, N, Cin, S, taps, dil, lens != nullptr, true);
+        const long need = (long)plan.splits * ((long)N * taps * Cin + N) * 4;
+        const bool slab = slab_env && ws && ws_bytes >= need && (one_ok || conv_ok) && (((uintptr_t)dW | (uintptr_t)dbias | (uintptr_t)ws) & 15) == 0 &&
+                          ((long)N * taps * Cin) % 4 == 0;
+        if (slab) { a.slab = ws; a.slab_stride = (long)N * taps * Cin + N; }
+        if (one_ok) {
+            const int S_eff = (lens && M % S == 0) ? S : M;
+            if (wg_waves1 == 8) launch_wgrad_bf16<1, 0, 8>(a, S_eff, 1, stream, slab ? &plan : nullptr);
+            else launch_wgrad_bf16<1, 0, 4>(a, S_eff, 1, stream, slab ? &plan : nullptr);
             bias_fused = true;
         }   // no taps, no lens: one "sequence" of M rows
-        else if (fast && 2 * dil <= 8 && M % S == 0) {
+        else if (conv_ok && slab && plan.share && (double)M * (lddy > ldx ? lddy : ldx) * 2 < 4.0e9 &&
+                 fs2_wgrad_tg_launch(a, plan, stream)) {
+            // the LDS-DMA tap-group kernel (fs2_wgrad.hip): groups of up to 5 taps share one set of X fragment reads
+            bias_fused = true;
+        }
+        else if (conv_ok) {
+            WgradPlan p3 = wgrad_plan(M, N, Cin, S, taps, dil, lens != nullptr, false);   // 3-tap groups, per-tap fragment reads
             const int g3 = taps / 3, rem = taps - 3 * g3;
+            const WgradPlan* pp = nullptr;
+            if (slab) {      // (dil > 1 with a workspace: the per-tap kernels with slab stores; same split depth rule)
+                p3.ups = plan.ups; p3.splits = plan.splits; pp = &p3;
+                const int tps = (S + 63) / 64; const long units = (long)(M / S) * tps;
+                p3.splits = fs2_cdiv(units, p3.ups);
+            }
             if (wg_waves == 8) {
-                if (rem == 0) launch_wgrad_bf16<3, 0, 8>(a, S, g3, stream);
-                else if (rem == 2) launch_wgrad_bf16<3, 2, 8>(a, S, g3, stream);
-                else launch_wgrad_bf16<3, 1, 8>(a, S, g3, stream);
+                if (rem == 0) launch_wgrad_bf16<3, 0, 8>(a, S, g3, stream, pp);
+                else if (rem == 2) launch_wgrad_bf16<3, 2, 8>(a, S, g3, stream, pp);
+                else launch_wgrad_bf16<3, 1, 8>(a, S, g3, stream, pp);
             } else {
-                if (rem == 0) launch_wgrad_bf16<3, 0, 4>(a, S, g3, stream);
-                else if (rem == 2) launch_wgrad_bf16<3, 2, 4>(a, S, g3, stream);
-                else launch_wgrad_bf16<3, 1, 4>(a, S, g3, stream);
+                if (rem == 0) launch_wgrad_bf16<3, 0, 4>(a, S, g3, stream, pp);
+                else if (rem == 2) launch_wgrad_bf16<3, 2, 4>(a, S, g3, stream, pp);
+                else launch_wgrad_bf16<3, 1, 4>(a, S, g3, stream, pp);
             }
             bias_fused = true;
         }
         else conv_wgrad_kernel<bf16_t><<<grid, 256, 0, stream>>>(a);
+        if (a.slab && bias_fused) {
+            const long nw = (long)N * taps * Cin;
+            const long nthreads = (nw + N + 3) / 4;
+            wgrad_finalize_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, stream>>>(dW, dbias, ws, a.slab_stride, plan.splits, nw, N);
+        }
     } else { fs2_set_error("conv_wgrad: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("conv_wgrad");
     if (dbias && !bias_fused) return fs2_colsum(dY, lddy, dbias, M, N, dtype, stream);   // slow paths: separate column-sum pass
     return FS2_OK;
+}
+
+extern "C" int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens,
+                              int M, int N, int Cin, int S, int taps, int dil, int pad, int dtype, hipStream_t stream) {
+    return conv_wgrad_impl(dY, lddy, X, ldx, dW, dbias, lens, M, N, Cin, S, taps, dil, pad, dtype, nullptr, 0, stream);
+}
+
+extern "C" int fs2_conv_wgrad_ws(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens,
+                                 int M, int N, int Cin, int S, int taps, int dil, int pad, int dtype, float* ws, long ws_bytes,
+                                 hipStream_t stream) {
+    return conv_wgrad_impl(dY, lddy, X, ldx, dW, dbias, lens, M, N, Cin, S, taps, dil, pad, dtype, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients)

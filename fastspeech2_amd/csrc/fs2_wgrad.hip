@@ -1,0 +1,317 @@
+// fs2_wgrad.hip - bf16 weight gradient of Conv1d (dil == 1, k >= 2) as an LDS-DMA, tap-sharing, split-K kernel (gfx950, round 3).
+//
+//   dW[n][j][c] += sum_m dY[m][n] * X[m + j - pad][c]            (autograd of transformer/SubLayers.py:87-88 w_1 k = 9,
+//                                                                  transformer/Layers.py:129-137 PostNet k = 5, model/modules.py:209-240 k = 3)
+// A TN contraction: the reduction index m is the SLOW dimension of both operands, so MFMA fragments (8 consecutive k = 8
+// consecutive rows of one column) come out of LDS through gfx950's transposing read ds_read_b64_tr_b16, as in the round-1/2
+// kernel (fs2_gemm.hip: conv_wgrad_bf16_kernel, which stays for one-tap launches, dil > 1 and callers without a workspace).
+// What round 2's profile said about that kernel (4.26 ms per step, 13-17 % MFMA busy, 1.8-2.5 LDS instructions
+// per MFMA, ~80 us atomic tail per launch; r01 ablation: register staging ALONE 130 us of a 310 us launch) and what changes here:
+//   * TAP SHARING.  One workgroup owns 128 (n) x 128 (c) outputs for a group of up to FIVE adjacent taps (k = 5: one group,
+//     k = 9: 5 + 4, k = 3: one) instead of three: the dY / X tiles of a K-tile are staged once (twice) instead of 2x (3x).  A lane
+//     of k-group h needs, for tap t, rows 8h + t .. 8h + t + 7 of its X column; it reads the 12-row run 8h .. 8h + 11 ONCE (three
+//     transposing reads) and takes tap t's operand out of registers: even t = dwords t/2 .. t/2 + 3 as they are, odd t = four
+//     v_alignbit_b32.  Per wave (64 n x 32 c x 5 taps) and 16-row sub-step: 7 LDS reads for 10 MFMAs (was 10 for 6).
+//   * LDS-DMA STAGING.  global_load_lds_dwordx4 (1 KiB per wave-instruction, lane-linear destination) into a ring of THREE
+//     34 KiB buffers, every wave issuing its 4 - 5 pieces of the tile two K-tiles ahead, counted vmcnt + ONE raw barrier per
+//     K-tile.  No staging registers (the 5-tap accumulators need 160 of the 256 a wave may hold at two waves per SIMD: the
+//     register-staged form spilled 57), no ds_write pass (16-byte LDS stores cost 13 cycles per wave-instruction on the VGPR ->
+//     LDS path: 430 cycles per K-tile), no address / mask VALU in the MFMA stream.  The 64-byte column groups are XOR-swizzled
+//     with (row & 3) so that the four rows of a transposing read fall into four bank quarters; the DMA destination being
+//     lane-linear, the permutation is applied to each lane's SOURCE column (same involution on the read side).
+//   * EDGES.  DMA cannot transform data, so rows outside the tile's sequence are fetched from clamped (always addressable) rows
+//     and then ZEROED IN LDS by the wave that fetched them: in the first / last K-tile of a sequence (2 of 15 at T = 925) each
+//     wave, once its own pieces have landed and before the barrier that publishes the tile, stores 16 zero bytes over every
+//     chunk of a dY row >= lens[b] or an X row outside [0, S) (lane l of a piece owns exactly its own 16 bytes).  The MFMA loop
+//     has ONE form (a masked instantiation of it beside the plain one made hipcc spill ~1500 registers).  Column tails (N or Cin
+//     not a multiple of 128) need nothing: their outputs are never stored.
+//   * ATOMIC-FREE SPLIT-K.  A split stores its partial tile with plain stores into its own f32 copy of dW (the caller's
+//     workspace); wgrad_finalize_kernel (fs2_gemm.hip) sums the splits in index order: bit-reproducible, no atomic tail.
+//     The bias gradient rides along: waves holding column block c = 0 sum their dY fragments with v_dot2c_f32_bf16.
+//   * Fully padded K-tiles (t0 >= lens[b]) are skipped BEFORE they are fetched (round 2 fetched them and skipped the MFMAs).
+#include "fs2_gemm.h"
+#include "fs2_wgrad.h"
+
+typedef short tg_s16x4 __attribute__((ext_vector_type(4)));
+typedef short tg_s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned tg_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned tg_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int TG_A_BYTES = 64 * 256;              // dY tile: 64 rows x 128 n (bf16)
+static constexpr int TG_X_ROWS = 72;                     // X tile: 64 rows + halo (4 taps) rounded up to whole 4-row DMA pieces
+static constexpr int TG_BUF_BYTES = TG_A_BYTES + TG_X_ROWS * 256;
+static constexpr int TG_NBUF = 3;
+
+template <int N> __device__ __forceinline__ void tg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// byte offset of element (row, col) in a swizzled [rows][128] bf16 tile image (col a multiple of 4: transposing reads take 8 bytes)
+__device__ __forceinline__ unsigned tg_off(int row, int col) {
+    return (unsigned)(row * 256 + ((((col >> 5) ^ (row & 3))) << 6) + ((col & 31) << 1));
+}
+struct TgUnit { int seq, j, u, tend; };                  // K-tile j of sequence seq (tend = its valid rows); u = seq * tps + j (u >= uend: none left)
+
+// lens[seq] through the SCALAR cache.  Written as a plain load hipcc emits global_load_dword + s_waitcnt vmcnt(0) for it (the
+// pointer sits in a by-value argument struct: no noalias / readonly facts) - and that wait drains the DMA ring several times per
+// K-tile.  An s_load counts on lgkmcnt and leaves the vector-memory queue alone.
+__device__ __forceinline__ int tg_sload(const int32_t* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+template <int NT>
+__device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char* smem, int tile_n, int tile_c, int tap0) {
+    static_assert(NT >= 1 && NT <= 5, "tap group of 1 .. 5 taps");
+    constexpr int NR = (8 + NT - 1 + 3) / 4;             // transposing reads per X run (4 rows each): 2 (NT = 1) or 3
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // 8 waves: wm = n half, wn = 32-column block of c
+    const int wm = wave >> 2, wn = wave & 3;
+    const int n0 = tile_n * 128, c0 = tile_c * 128;
+    const int shift0 = tap0 - a.pad;                     // tile row r of the X image = sequence row t0 + shift0 + r (dil == 1)
+    const int tps = (a.S + 63) >> 6;                     // K-tiles per sequence
+    const int nunits = (a.M / a.S) * tps;
+    const int ubeg = blockIdx.y * a.rows_per_split;      // units per split
+    const int uend = min(nunits, ubeg + a.rows_per_split);
+    const unsigned smem_u = lds_addr(smem);
+
+    // ---- K-tile list: live units of [ubeg, uend) in order (a unit is dead when its first row is at or beyond lens[seq])
+    auto tend_of = [&](int seq) -> int { return a.lens ? min(tg_sload(a.lens + seq), a.S) : a.S; };
+    auto settle = [&](TgUnit q) -> TgUnit {              // first live unit at or after q (q.tend is valid while q.u < uend)
+        while (q.u < uend && q.j * 64 >= q.tend) {
+            q.seq += 1; q.j = 0; q.u = q.seq * tps;
+            if (q.u < uend) q.tend = tend_of(q.seq);
+        }
+        if (q.u >= uend) q.u = uend;
+        return q;
+    };
+    auto next_of = [&](TgUnit q) -> TgUnit {
+        if (q.u >= uend) return q;
+        q.j += 1; q.u += 1;
+        if (q.j >= tps) { q.seq += 1; q.j = 0; if (q.u < uend) q.tend = tend_of(q.seq); }
+        return settle(q);
+    };
+
+    // ---- DMA geometry.  A 1 KiB piece = 4 tile rows; lane l writes LDS position (row l >> 4, 16-byte chunk l & 15), which must
+    // hold global chunk cg = swizzle^-1: the 64-byte group index XOR (row & 3) (row & 3 == l >> 4 for every piece).
+    // Wave w issues dY pieces w, w + 8 (rows 4w.., 4w + 32..), X pieces w, w + 8 and - waves 0, 1 - X piece 16 + w (rows 64 + 4w..).
+    const int lrow = lane >> 4, lq = lane & 15;
+    const int cg = (((lq >> 2) ^ lrow) << 2) | (lq & 3);
+    const unsigned acol_b = (unsigned)min(n0 + cg * 8, a.N - 8) * 2u;    // clamped into the matrix (tails feed outputs nobody stores)
+    const unsigned xcol_b = (unsigned)min(c0 + cg * 8, a.Cin - 8) * 2u;
+    const unsigned dy_rs = (unsigned)a.lddy * 2u, x_rs = (unsigned)a.ldx * 2u;
+    const bool w5 = wave < 2;
+    auto issue = [&](const TgUnit& q, int buf) {
+        const int t0 = q.j * 64;
+        const unsigned base = (unsigned)(q.seq * a.S);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_u + (unsigned)(buf * TG_BUF_BYTES + wave * 1024));   // (uniform: M0)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = min(t0 + 4 * wave + 32 * i + lrow, a.S - 1);
+            glds16_sbase((base + (unsigned)t) * dy_rs + acol_b, a.dY, dst + (unsigned)(i * 8192));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = min(max(t0 + shift0 + 4 * wave + 32 * i + lrow, 0), a.S - 1);
+            glds16_sbase((base + (unsigned)t) * x_rs + xcol_b, a.X, dst + (unsigned)(TG_A_BYTES + i * 8192));
+        }
+        if (w5) {
+            const int t = min(max(t0 + shift0 + 64 + 4 * wave + lrow, 0), a.S - 1);
+            glds16_sbase((base + (unsigned)t) * x_rs + xcol_b, a.X, dst + (unsigned)(TG_A_BYTES + 16384));
+        }
+    };
+
+    // ---- fragment addressing (per lane, computed once): lane = (li, g): 16-lane group g supplies the [4 rows][16 cols] block of a
+    // transposing read; h = g >> 1 is the MFMA k-group (rows 8h .. 8h + 7 of a 16-row sub-step)
+    const int li = lane & 15, g = lane >> 4, h = g >> 1;
+    const int rrow = 8 * h + (li >> 2);
+    const int acol = wm * 64 + 16 * (g & 1) + 4 * (li & 3);
+    const int bcol = wn * 32 + 16 * (g & 1) + 4 * (li & 3);
+    unsigned offA[2][2];                                 // [32-column block of n][rows 0-3 / 4-7 of the lane's 8]
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) offA[blk][hl] = tg_off(rrow + 4 * hl, acol + blk * 32);
+    const unsigned offB = TG_A_BYTES + tg_off(rrow, bcol);   // first row of the lane's run; reads q add 4 q rows = 1024 q bytes
+    typedef __attribute__((address_space(3))) tg_s16x4* lds_s4;
+    auto tr_read = [&](unsigned off) -> tg_s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(size_t)(smem_u + off)); };
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+    const bool do_bias = a.dbias != nullptr && tile_c == 0 && tap0 == 0 && wn == 0;      // wave-uniform
+    float bsum[2] = {0.f, 0.f};
+
+    tg_u32x4 af[2][2];                                   // [set][n block]: fragment double buffer over the 16-row sub-steps
+    tg_u32x2 run[2][NR];                                 // [set][read]: rows 8h + 4q .. + 3 of the lane's X column as two row-pair dwords
+    // one K-tile out of LDS buffer BUF (compile time: every ds_read offset is an immediate)
+    auto ktile = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        constexpr unsigned bufoff = BUF * TG_BUF_BYTES;
+        auto read_frags = [&](int set, int ks) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const tg_s16x4 lo = tr_read(offA[blk][0] + bufoff + ks * 4096);
+                const tg_s16x4 hi = tr_read(offA[blk][1] + bufoff + ks * 4096);
+                af[set][blk] = __builtin_bit_cast(tg_u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) run[set][r] = __builtin_bit_cast(tg_u32x2, tr_read(offB + bufoff + ks * 4096 + r * 1024));
+        };
+        auto mma = [&](int set) {
+            const tg_u32x4 av[2] = {af[set][0], af[set][1]};
+            unsigned R[2 * NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { R[2 * r] = run[set][r][0]; R[2 * r + 1] = run[set][r][1]; }
+            if (do_bias) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        bsum[blk] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tg_bf16x2, av[blk][d]),
+                                                                    __builtin_bit_cast(tg_bf16x2, 0x3f803f80u), bsum[blk], false);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                tg_u32x4 b;
+                if (t & 1) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) b[d] = __builtin_amdgcn_alignbit(R[(t >> 1) + d + 1], R[(t >> 1) + d], 16);
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) b[d] = R[(t >> 1) + d];
+                }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]), __builtin_bit_cast(bf16x8, b),
+                                                                         acc[t][mb], 0, 0, 0);
+            }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) read_frags((ks + 1) & 1, ks + 1);
+            mma(ks & 1);
+        }
+    };
+
+    // ---- pipeline: tile i lives in buffer i % 3; its DMA is issued two tiles ahead.  Per tile: wait for MY pieces of it (the
+    // next tile's stay in flight), ONE barrier (everybody's pieces landed; everybody has left the buffer the next issue overwrites)
+    TgUnit cur = TgUnit{ubeg / tps, ubeg % tps, ubeg, 0};
+    if (cur.u < uend) cur.tend = tend_of(cur.seq);
+    cur = settle(cur);
+    TgUnit nx1 = next_of(cur);
+    if (cur.u < uend) issue(cur, 0);
+    if (nx1.u < uend) issue(nx1, 1);
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    // rows of tile q (in buffer buf) that lie outside its sequence -> zeros, by the wave that fetched them (its pieces have landed)
+    auto zero_rows = [&](const TgUnit& q, int buf) {
+        const int t0 = q.j * 64, tend = q.tend;
+        unsigned char* bp = smem + buf * TG_BUF_BYTES + wave * 1024 + lane * 16;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (t0 + 4 * wave + 32 * i + lrow >= tend) *reinterpret_cast<uint4*>(bp + i * 8192) = z;
+            const int tx = t0 + shift0 + 4 * wave + 32 * i + lrow;
+            if (tx < 0 || tx >= a.S) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + i * 8192) = z;
+        }
+        if (w5) {
+            const int tx = t0 + shift0 + 64 + 4 * wave + lrow;
+            if (tx < 0 || tx >= a.S) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + 16384) = z;
+        }
+    };
+    auto step = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        const TgUnit nx2 = next_of(nx1);
+        if (nx1.u < uend) { if (w5) tg_wait_vm<5>(); else tg_wait_vm<4>(); }
+        else tg_wait_vm<0>();
+        const int t0 = cur.j * 64;
+        if ((t0 + 64 > cur.tend) || (t0 + shift0 < 0) || (t0 + shift0 + TG_X_ROWS > a.S)) zero_rows(cur, BUF);   // (block-uniform)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nx2.u < uend) issue(nx2, (BUF + 2) % 3);
+        ktile(bufc);
+        cur = nx1; nx1 = nx2;
+    };
+    while (cur.u < uend) {
+        step(I0{});
+        if (cur.u >= uend) break;
+        step(I1{});
+        if (cur.u >= uend) break;
+        step(I2{});
+    }
+
+    // ---- epilogue: acc[t][mb][r]: row n = wm*64 + mb*32 + (r&3) + 8*(r>>2) + 4*fh, column c = wn*32 + fl
+    const int fl = lane & 31, fh = lane >> 5;
+    float* const outW = a.slab ? a.slab + (size_t)blockIdx.y * a.slab_stride : a.dW;
+    if (do_bias) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const float tot = bsum[blk] + __shfl_xor(bsum[blk], 32, 64);          // the two k-groups of a column
+            const int n = n0 + wm * 64 + blk * 32 + fl;
+            if (fh == 0 && n < a.N) {
+                if (a.slab) outW[(size_t)a.N * a.taps * a.Cin + n] = tot;
+                else atomicAdd(a.dbias + n, tot);
+            }
+        }
+    }
+    const int c = c0 + wn * 32 + fl;
+    if (c < a.Cin) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n >= a.N) continue;
+                float* dst = outW + ((size_t)n * a.taps + tap0) * a.Cin + c;
+                if (a.slab) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) dst[(size_t)t * a.Cin] = acc[t][mb][r];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) atomicAdd(dst + (size_t)t * a.Cin, acc[t][mb][r]);
+                }
+            }
+    }
+}
+
+// grid.x = (n-tile, c-tile, tap group): the first a.g3 groups take NF taps each, one more group (if NR) the remaining NR taps;
+// grid.y = K-splits.  One 512-thread workgroup per CU (102 KiB of LDS, <= 256 registers per wave: two waves per SIMD).
+template <int NF, int NR>
+__global__ void __launch_bounds__(512, 2) conv_wgrad_tg_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 x [dY 64 rows | X 72 rows][256 B]
+    const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
+    int bx = blockIdx.x;
+    const int tile_n = bx % ntn; bx /= ntn;
+    const int tile_c = bx % ntc; bx /= ntc;
+    if (NR == 0 || bx < a.g3) wgrad_tg_body<NF>(a, smem, tile_n, tile_c, bx * NF);
+    else wgrad_tg_body<(NR ? NR : 1)>(a, smem, tile_n, tile_c, a.g3 * NF);
+}
+
+template <int NF, int NR>
+static void launch_tg(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
+    constexpr int dyn = TG_NBUF * TG_BUF_BYTES;
+    static Fs2DevOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_wgrad_tg_kernel<NF, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
+    a.g3 = p.g_first;
+    a.rows_per_split = p.ups;
+    conv_wgrad_tg_kernel<NF, NR><<<dim3((unsigned)p.tiles, (unsigned)p.splits), 512, dyn, stream>>>(a);
+}
+
+bool fs2_wgrad_tg_launch(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
+    const int nf = p.n_first, nr = p.n_rest;
+    if (nf == 5 && nr == 0) launch_tg<5, 0>(a, p, stream);
+    else if (nf == 5 && nr == 4) launch_tg<5, 4>(a, p, stream);
+    else if (nf == 4 && nr == 0) launch_tg<4, 0>(a, p, stream);
+    else if (nf == 4 && nr == 3) launch_tg<4, 3>(a, p, stream);
+    else if (nf == 3 && nr == 0) launch_tg<3, 0>(a, p, stream);
+    else if (nf == 2 && nr == 0) launch_tg<2, 0>(a, p, stream);
+    else return false;
+    return true;
+}

@@ -159,10 +159,39 @@ def tile_map(lens, B, S):
     return out
 
 
-def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None, dbias=None):
-    """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x;  dbias (Cout,) fp32 += column sums of dy (same pass)."""
+_wgrad_ws = {}
+
+
+def wgrad_workspace(device, stream_handle, nbytes):
+    """split-K scratch of the weight-gradient launches of ONE stream (launches on a stream run in order, so they share it); grown
+    on demand, never freed or shrunk (no allocator reuse hazard across streams)."""
+    key = (device.index, stream_handle)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20) // 4 + 4, device=device, dtype=torch.float32)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None, dbias=None, use_ws=True):
+    """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x;  dbias (Cout,) fp32 += column sums of dy (same pass).
+    bf16: split-K through a per-stream workspace (slab stores + one finalize launch, no atomics) unless use_ws is False."""
     M, N = dy.shape
     Cin = x.shape[1]
+    if use_ws and dy.dtype == torch.bfloat16 and M > 0:
+        need = _lib.load().fs2_conv_wgrad_ws_bytes(M, N, Cin, S, taps, dil, int(lens is not None), BF16)
+        if need > 0:
+            h = _stream()
+            ws = wgrad_workspace(dy.device, h, need)
+            if PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _lib.call("fs2_conv_wgrad_ws", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(dbias), _p(lens), M, N, Cin, S, taps,
+                      dil, pad, BF16, _p(ws), ws.numel() * 4, h)
+            if PROFILE is not None:
+                e1.record()
+                PROFILE.setdefault("conv_wgrad", []).append((2.0 * M * N * Cin * taps, e0, e1, taps, lens is not None, S))
+            return
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -98,6 +98,14 @@ int fs2_pack_dgrad_multi(const float* flat, void* wd_base, const int64_t* table,
  * lens (optional): the caller guarantees dY rows t >= lens[b] are zero, so their K-tiles are skipped. */
 int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens, int M,
                    int N, int Cin, int S, int taps, int dil, int pad, int dtype, fs2_stream_t stream);
+/* The same with a split-K workspace (round 3): every split stores its partial tile into its own f32 copy of dW inside `ws`
+ * (plain stores) and one more launch sums the splits into dW / dbias in index order - no atomics, bit-reproducible gradients,
+ * and (dil == 1) tap groups of up to 5 taps that share one set of X fragment reads.  ws: fs2_conv_wgrad_ws_bytes(...) bytes for
+ * the same shape, 16-byte aligned, any contents, not shared by launches that may run concurrently; NULL or too small = the
+ * atomic path of fs2_conv_wgrad.  bf16 only (fp32 ignores ws).  fs2_conv_wgrad_ws_bytes returns a size, not a status. */
+int fs2_conv_wgrad_ws_bytes(int M, int N, int Cin, int S, int taps, int dil, int has_lens, int dtype);
+int fs2_conv_wgrad_ws(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens, int M,
+                      int N, int Cin, int S, int taps, int dil, int pad, int dtype, float* ws, long ws_bytes, fs2_stream_t stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int fs2_colsum(const void* x, long ldx, float* out, int M, int N, int dtype, fs2_stream_t stream);
 

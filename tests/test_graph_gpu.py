@@ -3,7 +3,8 @@ forward + loss + backward + clip/Adam once and replays it.  Two host-side state 
 the dropout position (every replay drew the SAME masks) and the BatchNorm backward's ping-pong workspace parity (the C = 80
 layer reduced into a never-cleared workspace from the second replay on).  Here 3 eager warm-up steps + 4 replays are compared
 with 7 eager steps of an identically seeded model: per-step losses, Adam's first moments (linear in every gradient of every
-step), BatchNorm buffers."""
+step), BatchNorm buffers.  side_stream = 1: the EAGER steps run with the weight-gradient side stream (the default of train.py
+and bench.py); bench.capture_graph always captures on one stream (a forked capture measured 2.8e-3 off in this very test)."""
 import os
 import sys
 

@@ -89,6 +89,66 @@ def test_conv_grads(dev, dtype, tol, B, S, Cin, Cout, k, dil):
     assert rel_err(db, dyd.float().cpu().double().sum(0)) < 1e-4
 
 
+def _wgrad_ref(dy, x, Bq, S, k, pad):
+    xs, dys = x.float().view(Bq, S, -1).double(), dy.float().view(Bq, S, -1).double()
+    ref = torch.zeros(dys.shape[-1], k, xs.shape[-1], device=dy.device, dtype=torch.float64)
+    for j in range(k):
+        sh = j - pad
+        lo, hi = max(0, -sh), min(S, S - sh)
+        if hi > lo:
+            ref[:, j, :] = torch.einsum("bsn,bsc->nc", dys[:, lo:hi], xs[:, lo + sh:hi + sh])
+    return ref
+
+
+@pytest.mark.parametrize("Bq,S,Cin,Cout,k,pad", [
+    (3, 200, 128, 128, 5, 2), (5, 64, 256, 128, 9, 4), (4, 65, 128, 256, 9, 4), (2, 37, 128, 128, 3, 1), (6, 130, 80, 200, 5, 2),
+    (3, 131, 256, 80, 7, 3), (2, 500, 128, 128, 2, 0), (2, 129, 128, 128, 4, 1), (7, 63, 136, 128, 3, 1), (2, 300, 128, 128, 6, 2),
+    (2, 150, 128, 128, 8, 3), (3, 96, 128, 128, 11, 5), (4, 925, 256, 256, 9, 4), (3, 90, 128, 128, 3, 2), (2, 128, 512, 128, 1, 0)])
+def test_weight_gradient_workspace_path_edge_cases(dev, Bq, S, Cin, Cout, k, pad):
+    """The round-3 split-K weight gradient (fs2_conv_wgrad_ws: LDS-DMA tap-group kernel for k >= 2, slab stores + finalize for all)
+    against fp64: sequences shorter / exactly / just longer than one 64-row K-tile, tap groups 2 / 3 / 4 / 5 / 5+4 / 4+3 / 3+3 /
+    4+4 / 4+4+3, asymmetric padding, N / Cin that are not multiples of 128 (clamped DMA columns), ragged lens with EMPTY sequences
+    (skipped K-tiles, rows zeroed in LDS), += into a non-zero gradient, a NaN-poisoned workspace (every slab word that is read
+    was written), bit-reproducibility, and agreement with the atomic path."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(S * 7 + k)
+    M = Bq * S
+    x = torch.randn(M, Cin, generator=g).to(dev).to(torch.bfloat16)
+    dy_full = torch.randn(M, Cout, generator=g).to(dev)
+    lens = torch.randint(0, S + 1, (Bq,), generator=g).to(torch.int32)
+    lens[0] = S
+    if Bq > 2:
+        lens[1] = 0
+    for use_lens in (False, True):
+        ld = lens.to(dev) if use_lens else None
+        valid = (torch.arange(S, device=dev).unsqueeze(0) < lens.to(dev).unsqueeze(1)).reshape(-1, 1) if use_lens else 1.0
+        dy = (dy_full * valid).to(torch.bfloat16)                              # contract: gradient rows >= lens are zero
+        ref = _wgrad_ref(dy, x, Bq, S, k, pad)
+        bref = dy.float().double().sum(0)
+        scale, bscale = max(ref.abs().max().item(), 1e-6), max(bref.abs().max().item(), 1e-6)
+        init = torch.randn(Cout, k, Cin, generator=g).to(dev)
+        binit = torch.randn(Cout, generator=g).to(dev)
+        outs = []
+        for rep in range(2):
+            for key, ws in list(ops._wgrad_ws.items()):
+                ws.fill_(float("nan"))
+            dw, db = init.clone(), binit.clone()
+            ops.conv_wgrad(dy, x, dw, S, taps=k, pad=pad, lens=ld, dbias=db)
+            if rep == 0:                                                   # (first call may have just created the workspace: poison + redo)
+                for key, ws in list(ops._wgrad_ws.items()):
+                    ws.fill_(float("nan"))
+                dw, db = init.clone(), binit.clone()
+                ops.conv_wgrad(dy, x, dw, S, taps=k, pad=pad, lens=ld, dbias=db)
+            outs.append((dw, db))
+            err = (dw.double() - init.double() - ref).abs().max().item()
+            assert err <= 2e-5 * scale + 2e-6, (use_lens, err, scale)
+            assert ((db.double() - binit.double() - bref).abs().max().item()) <= 2e-5 * bscale + 2e-6
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # no atomics: bit-reproducible
+        dwa, dba = init.clone(), binit.clone()
+        ops.conv_wgrad(dy, x, dwa, S, taps=k, pad=pad, lens=ld, dbias=dba, use_ws=False)         # round-1/2 atomic kernels
+        assert (dwa.double() - init.double() - ref).abs().max().item() <= 2e-5 * scale + 2e-6
+
+
 def attn_ref(qkv, lens, B, S, H):
     dk = 128
     q, k, v = qkv.view(B, S, 3, H, dk).unbind(2)
