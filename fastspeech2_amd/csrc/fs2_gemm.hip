@@ -1579,7 +1579,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) conv_wgrad_bf16_kern
 }
 
 extern "C" int fs2_conv_wgrad_ws_bytes(int M, int N, int Cin, int S, int taps, int dil, int has_lens, int dtype) {
-    if (dtype != FS2_BF16 || M <= 0 || N <= 0 || Cin <= 0 || S <= 0 || taps <= 0) return 0;
+    if (dtype != FS2_BF16 || M <= 0 || N <= 0 || Cin <= 0 || S <= 0 || taps <= 1) return 0;   // (one-tap launches: see conv_wgrad_impl)
     const WgradPlan p = wgrad_plan(M, N, Cin, S, taps, dil, has_lens != 0, true);
     const long b = (long)p.splits * ((long)N * taps * Cin + N) * 4;
     return b > 0x7fffffffL ? 0 : (int)b;                 // (a single slab beyond 2 GB: no workspace -> the atomic path)
@@ -1662,15 +1662,44 @@ static int conv_wgrad_impl(const void* dY, long lddy, const void* X, long ldx, f
         static const int slab_env = fs2_dev_env("FS2_WGRAD_SLAB", 1);   // dev A/B: 0 = atomics even with a workspace
         WgradPlan plan = wgrad_plan(M, N, Cin, S, taps, dil, lens != nullptr, true);
         const long need = (long)plan.splits * ((long)N * taps * Cin + N) * 4;
-        const bool slab = slab_env && ws && ws_bytes >= need && (one_ok || conv_ok) && (((uintptr_t)dW | (uintptr_t)dbias | (uintptr_t)ws) & 15) == 0 &&
+        // One-tap (Linear) gradients stay on the atomic path: they are short HBM-bound launches whose split depth was tuned for
+        // it, and with slabs they measured SLOWER on the first round-3 run (r03b: fc 28 -> 42 us, mel 19 -> 44, encoder shapes
+        // 17-21 -> 22-23; only the K = 1024 FFN shape gained, 70 -> 62): 64-128 splits of a 64 KB tile turn the finalize pass into
+        // a latency chain.  one_slab (dev builds) re-enables it for A/B.
+        static const int one_slab = fs2_dev_env("FS2_WGRAD_SLAB1", 0);
+        const bool slab = slab_env && ws && ws_bytes >= need && ((one_ok && one_slab) || conv_ok) && (((uintptr_t)dW | (uintptr_t)dbias | (uintptr_t)ws) & 15) == 0 &&
                           ((long)N * taps * Cin) % 4 == 0;
         if (slab) { a.slab = ws; a.slab_stride = (long)N * taps * Cin + N; }
         if (one_ok) {
-            const int S_eff = (lens && M % S == 0) ? S : M;
-            if (wg_waves1 == 8) launch_wgrad_bf16<1, 0, 8>(a, S_eff, 1, stream, slab ? &plan : nullptr);
-            else launch_wgrad_bf16<1, 0, 4>(a, S_eff, 1, stream, slab ? &plan : nullptr);
+            const int S_eff = (lens && M % S == 0) ? S : M;                 // no taps, no lens: one "sequence" of M rows
+            // round 3: the LDS-DMA kernel's one-tap form (four 32 KiB buffers: three K-tiles in flight per CU instead of the
+            // register-staged kernel's two) with the ATOMIC epilogue - these launches are HBM-bound and short, slabs lose here
+            static const int one_tg = fs2_dev_env("FS2_WGRAD_TG1", 1);
+            // workgroups to aim for: 128 (same-box sweeps of the whole step, r03e / r03f: 64: 8.73, 96: 8.68, 128: 8.66, 160: 8.66,
+            // 192: 9.53 vs 9.47 at 128 on the other box, 256: 8.73, 384+: worse; the register-staged kernel: 8.74): a workgroup holds
+            // 128 KiB of LDS, i.e. a whole CU that the data-gradient chain's persistent kernels cannot use meanwhile
+            static const int one_wgs = fs2_dev_env("FS2_WGRAD_TG1_WGS", 128);
+            bool done = false;
+            if (one_tg && !slab && (double)M * (lddy > ldx ? lddy : ldx) * 2 < 4.0e9) {
+                WgradPlan p1 = {};
+                p1.g_first = 1; p1.n_first = 1; p1.n_rest = 0; p1.share = 1;
+                p1.tiles = fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128);
+                p1.units = (M / S_eff) * ((S_eff + 63) / 64);
+                long want = p1.tiles >= one_wgs ? 1 : (one_wgs + p1.tiles / 2) / p1.tiles;
+                const long max_by_units = p1.units / 8 > 0 ? p1.units / 8 : 1;
+                if (want > max_by_units) want = max_by_units;
+                p1.ups = (int)((p1.units + want - 1) / want);
+                p1.splits = fs2_cdiv(p1.units, p1.ups);
+                WgradArgs a1 = a;
+                a1.S = S_eff;
+                done = fs2_wgrad_tg_launch(a1, p1, stream);
+            }
+            if (!done) {
+                if (wg_waves1 == 8) launch_wgrad_bf16<1, 0, 8>(a, S_eff, 1, stream, slab ? &plan : nullptr);
+                else launch_wgrad_bf16<1, 0, 4>(a, S_eff, 1, stream, slab ? &plan : nullptr);
+            }
             bias_fused = true;
-        }   // no taps, no lens: one "sequence" of M rows
+        }
         else if (conv_ok && slab && plan.share && (double)M * (lddy > ldx ? lddy : ldx) * 2 < 4.0e9 &&
                  fs2_wgrad_tg_launch(a, plan, stream)) {
             // the LDS-DMA tap-group kernel (fs2_wgrad.hip): groups of up to 5 taps share one set of X fragment reads

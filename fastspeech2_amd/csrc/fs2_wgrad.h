@@ -35,7 +35,10 @@ static inline WgradPlan wgrad_plan(int M, int N, int Cin, int S, int taps, int d
     p.tiles = fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128) * groups;
     p.units = (M / S_eff) * ((S_eff + 63) / 64);
     if (slab) {
-        const int cus = 256;
+        // workgroups to aim for: 192, not one per CU - these launches run on the side stream NEXT TO the data-gradient chain, whose
+        // persistent kernels need whole CUs (r03d same-box sweep of the whole step, two rounds: 64: 10.56 ms, 96: 9.55, 128: 9.31,
+        // 160: 9.23, 192: 9.22, 256: 9.27, 384 .. 1024: 9.41 - 9.45; the round-2 atomic kernels: 9.44; no weight gradients: 7.88)
+        static const int cus = fs2_dev_env("FS2_WGRAD_TG_WGS", 192);
         long want = p.tiles >= cus ? 1 : (cus + p.tiles / 2) / p.tiles;       // round(cus / tiles)
         const long max_by_units = p.units / 8 > 0 ? p.units / 8 : 1;
         if (want > max_by_units) want = max_by_units;

@@ -39,9 +39,14 @@ typedef unsigned tg_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int TG_A_BYTES = 64 * 256;              // dY tile: 64 rows x 128 n (bf16)
-static constexpr int TG_X_ROWS = 72;                     // X tile: 64 rows + halo (4 taps) rounded up to whole 4-row DMA pieces
-static constexpr int TG_BUF_BYTES = TG_A_BYTES + TG_X_ROWS * 256;
-static constexpr int TG_NBUF = 3;
+// X tile: 64 rows (+ halo of NT - 1 <= 4 rows, rounded up to whole 4-row DMA pieces: 72) x 128 c
+template <int NT> struct TgCfg {
+    static constexpr int X_ROWS = NT == 1 ? 64 : 72;
+    static constexpr int BUF_BYTES = TG_A_BYTES + X_ROWS * 256;
+    // ring depth: tile i is fetched NBUF - 1 tiles ahead.  One-tap launches are HBM-bound (a 32 KiB tile feeds 16 MFMAs per
+    // wave): FOUR 32 KiB buffers keep three tiles in flight per CU (the register-staged kernel held two and moved 1.6 TB/s)
+    static constexpr int NBUF = NT == 1 ? 4 : 3;
+};
 
 template <int N> __device__ __forceinline__ void tg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -64,6 +69,7 @@ template <int NT>
 __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char* smem, int tile_n, int tile_c, int tap0) {
     static_assert(NT >= 1 && NT <= 5, "tap group of 1 .. 5 taps");
     constexpr int NR = (8 + NT - 1 + 3) / 4;             // transposing reads per X run (4 rows each): 2 (NT = 1) or 3
+    constexpr int TG_X_ROWS = TgCfg<NT>::X_ROWS, TG_BUF_BYTES = TgCfg<NT>::BUF_BYTES, NBUF = TgCfg<NT>::NBUF, D = NBUF - 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // 8 waves: wm = n half, wn = 32-column block of c
     const int wm = wave >> 2, wn = wave & 3;
@@ -100,7 +106,7 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
     const unsigned acol_b = (unsigned)min(n0 + cg * 8, a.N - 8) * 2u;    // clamped into the matrix (tails feed outputs nobody stores)
     const unsigned xcol_b = (unsigned)min(c0 + cg * 8, a.Cin - 8) * 2u;
     const unsigned dy_rs = (unsigned)a.lddy * 2u, x_rs = (unsigned)a.ldx * 2u;
-    const bool w5 = wave < 2;
+    const bool w5 = TG_X_ROWS > 64 && wave < 2;         // (NT == 1: no halo pieces, 4 pieces per wave)
     auto issue = [&](const TgUnit& q, int buf) {
         const int t0 = q.j * 64;
         const unsigned base = (unsigned)(q.seq * a.S);
@@ -168,12 +174,18 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
 #pragma unroll
             for (int r = 0; r < NR; ++r) { R[2 * r] = run[set][r][0]; R[2 * r + 1] = run[set][r][1]; }
             if (do_bias) {
+                // (each dword goes through a named scalar: written as av[blk][d] inside the bit_cast, hipcc 7.2 fed element 0 to all
+                // four v_dot2c - seen in the ISA and as an O(1)-wrong bias gradient on the first GPU run)
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d)
-                        bsum[blk] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tg_bf16x2, av[blk][d]),
-                                                                    __builtin_bit_cast(tg_bf16x2, 0x3f803f80u), bsum[blk], false);
+                for (int blk = 0; blk < 2; ++blk) {
+                    const unsigned e0 = av[blk][0], e1 = av[blk][1], e2 = av[blk][2], e3 = av[blk][3];
+                    float t = bsum[blk];
+                    t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tg_bf16x2, e0), __builtin_bit_cast(tg_bf16x2, 0x3f803f80u), t, false);
+                    t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tg_bf16x2, e1), __builtin_bit_cast(tg_bf16x2, 0x3f803f80u), t, false);
+                    t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tg_bf16x2, e2), __builtin_bit_cast(tg_bf16x2, 0x3f803f80u), t, false);
+                    t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tg_bf16x2, e3), __builtin_bit_cast(tg_bf16x2, 0x3f803f80u), t, false);
+                    bsum[blk] = t;
+                }
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -199,52 +211,68 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
         }
     };
 
-    // ---- pipeline: tile i lives in buffer i % 3; its DMA is issued two tiles ahead.  Per tile: wait for MY pieces of it (the
-    // next tile's stay in flight), ONE barrier (everybody's pieces landed; everybody has left the buffer the next issue overwrites)
-    TgUnit cur = TgUnit{ubeg / tps, ubeg % tps, ubeg, 0};
-    if (cur.u < uend) cur.tend = tend_of(cur.seq);
-    cur = settle(cur);
-    TgUnit nx1 = next_of(cur);
-    if (cur.u < uend) issue(cur, 0);
-    if (nx1.u < uend) issue(nx1, 1);
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    // rows of tile q (in buffer buf) that lie outside its sequence -> zeros, by the wave that fetched them (its pieces have landed)
-    auto zero_rows = [&](const TgUnit& q, int buf) {
-        const int t0 = q.j * 64, tend = q.tend;
+    // ---- pipeline: tile i lives in buffer i % NBUF; its DMA is issued D = NBUF - 1 tiles ahead.  Per tile: wait for MY pieces of it
+    // (the later tiles' stay in flight), ONE barrier (everybody's pieces landed; everybody has left the buffer the next issue overwrites)
+    TgUnit q[D];                                          // q[0] = the tile being multiplied next, q[1 ..] = issued ahead of it
+    q[0] = TgUnit{ubeg / tps, ubeg % tps, ubeg, 0};
+    if (q[0].u < uend) q[0].tend = tend_of(q[0].seq);
+    q[0] = settle(q[0]);
+#pragma unroll
+    for (int i = 1; i < D; ++i) q[i] = next_of(q[i - 1]);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (q[i].u < uend) issue(q[i], i);
+    // rows of tile u (in buffer buf) that lie outside its sequence -> zeros, by the wave that fetched them (its pieces have landed)
+    auto zero_rows = [&](const TgUnit& u, int buf) {
+        const int t0 = u.j * 64, tend = u.tend;
+        const int xdead = tend - t0 + NT - 1;             // first X tile row all of whose partner dY rows are >= tend
         unsigned char* bp = smem + buf * TG_BUF_BYTES + wave * 1024 + lane * 16;
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (t0 + 4 * wave + 32 * i + lrow >= tend) *reinterpret_cast<uint4*>(bp + i * 8192) = z;
-            const int tx = t0 + shift0 + 4 * wave + 32 * i + lrow;
-            if (tx < 0 || tx >= a.S) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + i * 8192) = z;
+            // X tile row r pairs with dY rows r - t, t < NT: outside [0, S) it is not this sequence's data; at r >= xdead every
+            // partner row is beyond the valid part (a zero) - and 0 x whatever the producer left in a padded row (attention
+            // output, skipped tiles: possibly NaN bit patterns) must stay 0, so those rows are zeroed too
+            const int rx = 4 * wave + 32 * i + lrow, tx = t0 + shift0 + rx;
+            if (tx < 0 || tx >= a.S || rx >= xdead) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + i * 8192) = z;
         }
         if (w5) {
-            const int tx = t0 + shift0 + 64 + 4 * wave + lrow;
-            if (tx < 0 || tx >= a.S) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + 16384) = z;
+            const int rx = 64 + 4 * wave + lrow, tx = t0 + shift0 + rx;
+            if (tx < 0 || tx >= a.S || rx >= xdead) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + 16384) = z;
         }
     };
     auto step = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
-        const TgUnit nx2 = next_of(nx1);
-        if (nx1.u < uend) { if (w5) tg_wait_vm<5>(); else tg_wait_vm<4>(); }
-        else tg_wait_vm<0>();
-        const int t0 = cur.j * 64;
-        if ((t0 + 64 > cur.tend) || (t0 + shift0 < 0) || (t0 + shift0 + TG_X_ROWS > a.S)) zero_rows(cur, BUF);   // (block-uniform)
+        const TgUnit nxt = next_of(q[D - 1]);
+        int ahead = 0;                                    // tiles issued after q[0] whose pieces may stay in flight
+#pragma unroll
+        for (int i = 1; i < D; ++i) ahead += (q[i].u < uend) ? 1 : 0;
+        if (ahead == 0) tg_wait_vm<0>();
+        else if (ahead == 1) { if (w5) tg_wait_vm<5>(); else tg_wait_vm<4>(); }
+        else if (ahead == 2) { if (w5) tg_wait_vm<10>(); else tg_wait_vm<8>(); }
+        else { if (w5) tg_wait_vm<15>(); else tg_wait_vm<12>(); }
+        const int t0 = q[0].j * 64;
+        if ((t0 + 64 > q[0].tend) || (t0 + shift0 < 0) || (t0 + shift0 + TG_X_ROWS > a.S)) zero_rows(q[0], BUF);   // (block-uniform)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (nx2.u < uend) issue(nx2, (BUF + 2) % 3);
+        if (nxt.u < uend) issue(nxt, (BUF + D) % NBUF);
         ktile(bufc);
-        cur = nx1; nx1 = nx2;
+#pragma unroll
+        for (int i = 0; i + 1 < D; ++i) q[i] = q[i + 1];
+        q[D - 1] = nxt;
     };
-    while (cur.u < uend) {
-        step(I0{});
-        if (cur.u >= uend) break;
-        step(I1{});
-        if (cur.u >= uend) break;
-        step(I2{});
+    static_assert(NBUF == 3 || NBUF == 4, "ring of 3 or 4 buffers");
+    while (q[0].u < uend) {
+        step(std::integral_constant<int, 0>{});
+        if (q[0].u >= uend) break;
+        step(std::integral_constant<int, 1>{});
+        if (q[0].u >= uend) break;
+        step(std::integral_constant<int, 2>{});
+        if (NBUF == 4) {
+            if (q[0].u >= uend) break;
+            step(std::integral_constant<int, (NBUF == 4 ? 3 : 0)>{});
+        }
     }
 
     // ---- epilogue: acc[t][mb][r]: row n = wm*64 + mb*32 + (r&3) + 8*(r>>2) + 4*fh, column c = wn*32 + fl
@@ -285,7 +313,7 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
 // grid.y = K-splits.  One 512-thread workgroup per CU (102 KiB of LDS, <= 256 registers per wave: two waves per SIMD).
 template <int NF, int NR>
 __global__ void __launch_bounds__(512, 2) conv_wgrad_tg_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 x [dY 64 rows | X 72 rows][256 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF x [dY 64 rows | X 64 / 72 rows][256 B]
     const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
     int bx = blockIdx.x;
     const int tile_n = bx % ntn; bx /= ntn;
@@ -296,7 +324,8 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad_tg_kernel(WgradArgs a) {
 
 template <int NF, int NR>
 static void launch_tg(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
-    constexpr int dyn = TG_NBUF * TG_BUF_BYTES;
+    constexpr int dyn = (TgCfg<NF>::NBUF * TgCfg<NF>::BUF_BYTES > TgCfg<(NR ? NR : NF)>::NBUF * TgCfg<(NR ? NR : NF)>::BUF_BYTES)
+                            ? TgCfg<NF>::NBUF * TgCfg<NF>::BUF_BYTES : TgCfg<(NR ? NR : NF)>::NBUF * TgCfg<(NR ? NR : NF)>::BUF_BYTES;
     static Fs2DevOnce once;
     once.run([&] { (void)hipFuncSetAttribute((const void*)conv_wgrad_tg_kernel<NF, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
     a.g3 = p.g_first;
@@ -312,6 +341,7 @@ bool fs2_wgrad_tg_launch(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
     else if (nf == 4 && nr == 3) launch_tg<4, 3>(a, p, stream);
     else if (nf == 3 && nr == 0) launch_tg<3, 0>(a, p, stream);
     else if (nf == 2 && nr == 0) launch_tg<2, 0>(a, p, stream);
+    else if (nf == 1 && nr == 0) launch_tg<1, 0>(a, p, stream);
     else return false;
     return true;
 }

@@ -160,15 +160,23 @@ def tile_map(lens, B, S):
 
 
 _wgrad_ws = {}
+_wgrad_ws_retired = []
+_WGRAD_WS_MIN = 100 << 20            # the planner caps a launch's slabs at 96 MB: one allocation per stream covers every shape
 
 
 def wgrad_workspace(device, stream_handle, nbytes):
-    """split-K scratch of the weight-gradient launches of ONE stream (launches on a stream run in order, so they share it); grown
-    on demand, never freed or shrunk (no allocator reuse hazard across streams)."""
+    """split-K scratch of the weight-gradient launches of ONE stream (launches on a stream run in order, so they share it).
+    Allocated once per stream at the planner's cap.  Should a larger one ever be needed, the old buffer is RETIRED, not freed:
+    it was allocated from the pool of torch's current stream (the step's main stream) but is used by kernels queued on
+    `stream_handle` (the engine's side stream); handing it back would let the caching allocator give its memory to the next
+    main-stream tensor while a queued weight-gradient kernel still writes slabs there (round-3 finding: the first step of a run
+    grew the workspace three times and non-finite gradients appeared in whatever was allocated next - tools/dbg_ddp.py)."""
     key = (device.index, stream_handle)
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20) // 4 + 4, device=device, dtype=torch.float32)
+        if ws is not None:
+            _wgrad_ws_retired.append(ws)
+        ws = torch.empty(max(nbytes, _WGRAD_WS_MIN) // 4 + 4, device=device, dtype=torch.float32)
         _wgrad_ws[key] = ws
     return ws
 

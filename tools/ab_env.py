@@ -19,6 +19,11 @@ def one():
         model._engine.defer_ln_reduce = False
     if os.environ.get("AB_BRANCH") == "0":
         model._engine.concurrent_branches = False
+    if os.environ.get("AB_SKIP_WGRAD") == "1":              # the critical chain alone (weight gradients not computed at all)
+        from fastspeech2_amd import ops
+        ops.conv_wgrad = lambda *a, **k: None
+    if os.environ.get("AB_SIDE") == "0":
+        model._engine.use_side_stream = False
     # (stream priorities: torch.cuda.Stream.priority_range() is (0, -1) on this stack - the step runs on -1, the side stream on 0;
     # there is no lower level to try)
     step, _ = bench.make_step(model, loss_fn, opt, b, None)
