@@ -17,7 +17,7 @@ all: $(LIB) $(AIDLIB)
 $(AIDLIB): tests/aids/fs2_testaid.cpp $(CSRC)/fs2_sched.h include/fs2hip_testaid.h
 	g++ -O2 -std=c++17 -shared -fPIC -I$(CSRC) -Iinclude -o $@ tests/aids/fs2_testaid.cpp
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h $(CSRC)/fs2_sched.h $(CSRC)/fs2_wgrad.h
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h $(CSRC)/fs2_sched.h $(CSRC)/fs2_wgrad.h $(CSRC)/fs2_gemm_epi.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -38,7 +38,7 @@ clean:
 DEVOBJ := build/obj_dev
 DEVOBJS := $(patsubst $(CSRC)/%.hip,$(DEVOBJ)/%.o,$(SRCS)) $(DEVOBJ)/fs2_api.o
 DEVLIB := fastspeech2_amd/libfs2hip_dev.so
-$(DEVOBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h $(CSRC)/fs2_sched.h $(CSRC)/fs2_wgrad.h
+$(DEVOBJ)/%.o: $(CSRC)/%.hip $(CSRC)/fs2_common.h $(CSRC)/fs2_gemm.h $(CSRC)/fs2_sched.h $(CSRC)/fs2_wgrad.h $(CSRC)/fs2_gemm_epi.h
 	@mkdir -p $(DEVOBJ)
 	$(HIPCC) $(HIPFLAGS) -DFS2_DEV -c $< -o $@
 $(DEVOBJ)/fs2_api.o: $(CSRC)/fs2_api.cpp

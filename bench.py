@@ -304,7 +304,7 @@ def synth_cpu_baseline(args, lens8, threads):
 
 
 SYNTH_NAMES = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel",
-               5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)"}
+               5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)", 7: "conv_gemm_w_kernel (taps == 1, N % 256 == 0)"}
 
 
 def synth_measure(args, device, rank, world, steps, warmup, want_roofline):
@@ -608,8 +608,7 @@ def main():
         model._engine.use_side_stream = side
         rec = prof.get("conv_gemm", [])
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        names = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel",
-                 5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)"}
+        names = SYNTH_NAMES
         # fraction of the padded rows that are valid, per sequence length (launches that pass `lens` skip fully padded tiles:
         # `achieved` counts the reference's padded algorithmic FLOPs, `achieved_valid_rows` only those of valid rows)
         vfrac = {int(b["max_mel_len"]): float(b["mel_lens"].sum()) / (args.batch * b["max_mel_len"]),

@@ -148,5 +148,6 @@ __device__ __forceinline__ float fs2_drop_scale(uint64_t seed, uint32_t idx, flo
 #define FS2_GEMM_SKINNY 4
 #define FS2_GEMM_PERSIST 5
 #define FS2_GEMM_PERSIST_1TAP 6
+#define FS2_GEMM_WIDE_1TAP 7
 #endif
 static inline int fs2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

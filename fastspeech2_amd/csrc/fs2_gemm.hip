@@ -942,6 +942,9 @@ static void launch_skinny(const ConvGemmArgs& a, hipStream_t stream) {
     conv_skinny_kernel<C><<<(unsigned)fs2_cdiv(a.M, 128), 256, SkinnyCfg<C>::LDS, stream>>>(a);
 }
 
+// defined in fs2_gemm_w.hip
+bool fs2_conv_gemm_w_ok(const ConvGemmArgs& a, bool has_map, int dtype);
+void fs2_conv_gemm_w_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream);
 // defined in fs2_gemm_p.hip
 bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks);
 void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream, int abl, int ks, float* ws,
@@ -980,6 +983,9 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map) {
     // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
     static const int ksplit_on = fs2_dev_env("FS2_GEMM_KSPLIT", 1);
     p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= 32;
+    // wide-tile one-tap kernel (fs2_gemm_w.hip): N a multiple of 256 - the Linear layers of the FFT blocks and their data gradients
+    static const int w_on = fs2_dev_env("FS2_GEMM_W", 1);
+    if (w_on && !skinny && fs2_conv_gemm_w_ok(a, has_map, dtype)) { p.variant = FS2_GEMM_WIDE_1TAP; return p; }
     p.variant = skinny ? FS2_GEMM_SKINNY : (persist ? (taps == 1 ? FS2_GEMM_PERSIST_1TAP : FS2_GEMM_PERSIST) : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN)));
     return p;
 }
@@ -1028,6 +1034,8 @@ static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* b
         if (Cin == 32) launch_skinny<32>(a, stream);
         else if (Cin == 64) launch_skinny<64>(a, stream);
         else launch_skinny<128>(a, stream);
+    } else if (pk.variant == FS2_GEMM_WIDE_1TAP) {
+        fs2_conv_gemm_w_launch(a, tile_map, stream);
     } else if (pk.variant == FS2_GEMM_PERSIST || pk.variant == FS2_GEMM_PERSIST_1TAP) {
         static const int abl = fs2_dev_env("FS2_GEMM_ABL", 0);
         fs2_conv_gemm_p_launch(a, tile_map, stream, abl, 1, nullptr, tail_ws);

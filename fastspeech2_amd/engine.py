@@ -69,6 +69,7 @@ class Engine:
         self.defer_ln_reduce = True
         self._pack_pending = False
         self._bn_ws = {}
+        self._bn_eval = {}
         self._tail_ws = [None, None]
         self._on_side = False
         self.concurrent_branches = True
@@ -239,6 +240,18 @@ class Engine:
             z = torch.zeros(3, 2 * C, device=self.device, dtype=torch.float32)
             ws = self._bn_ws[C] = [z[0], z[1], z[2], 0]
         return ws
+
+    def _bn_eval_stats(self, pre):
+        """[running_mean | rsqrt(running_var + eps)] of an eval-mode BatchNorm layer, cached until the buffers change (torch bumps a
+        tensor's _version on every in-place write: load_state_dict, a training step).  Was three tiny torch launches (add, rsqrt,
+        cat) per PostNet layer and synthesis batch - 15 of a synthesis step's launches."""
+        rm, rv = self.Bf[pre + "1.running_mean"], self.Bf[pre + "1.running_var"]
+        key = (rm.data_ptr(), rm._version, rv.data_ptr(), rv._version)
+        hit = self._bn_eval.get(pre)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([rm, torch.rsqrt(rv + 1e-5)]))
+            self._bn_eval[pre] = hit
+        return hit[1]
 
     @staticmethod
     def _tmap(lens):
@@ -606,7 +619,7 @@ class Engine:
                                                     seed_dev=_seed_pair(200 + i, seed_dev)[1], ws=self._bn_workspace(c.shape[1])[0],
                                                     num_batches_tracked=self.Bf[pre + "1.num_batches_tracked"])
             else:
-                mean_rstd = torch.cat([self.Bf[pre + "1.running_mean"], torch.rsqrt(self.Bf[pre + "1.running_var"] + 1e-5)])
+                mean_rstd = self._bn_eval_stats(pre)
                 h_out = torch.empty_like(c)
                 ops._lib.call("fs2_bn_apply", c.data_ptr(), mean_rstd.data_ptr(), P[pre + "1.weight"].data_ptr(),
                               P[pre + "1.bias"].data_ptr(), res.data_ptr() if res is not None else None, h_out.data_ptr(),
