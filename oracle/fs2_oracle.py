@@ -17,6 +17,50 @@ import torch
 import torch.nn.functional as F
 
 
+# ------------------------------------------------------------------------------------------------ storage emulation
+# The product's bf16 path STORES every activation between two kernels in bfloat16 (and, in backward, the gradient of that
+# activation).  `with storage(round_st_bf16):` makes the functions below apply the given function at exactly those points - the
+# bf16 EMULATION the whole-step bf16 bars are derived from (tests/golden/make_bf16_bars.py).  Outside the context nothing is
+# applied and every function is the plain fp32 / fp64 restatement pinned by the goldens.
+_STORE = None
+
+
+class storage:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _STORE
+        self.prev, _STORE = _STORE, self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global _STORE
+        _STORE = self.prev
+        return False
+
+
+def _st(x):
+    return x if _STORE is None else _STORE(x)
+
+
+class _RoundST(torch.autograd.Function):
+    """bf16 rounding of a stored activation with a straight-through backward that rounds the GRADIENT the same way (the product
+    keeps the gradient of a bf16 activation in bf16 too)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def round_st_bf16(x):
+    return _RoundST.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------ helpers
 def sinusoid_table(n_position, d_hid):
     """transformer/Models.py:10-30 — float64 numpy angles, sin on even / cos on odd dims, cast to float32."""
@@ -48,24 +92,24 @@ def multi_head_attention(sd, pre, x, key_pad_mask, n_head, dropout_p, training):
     """transformer/SubLayers.py:29-57 + transformer/Modules.py:14-25 (post-LN, key-padding mask, no attn dropout)."""
     B, S, D = x.shape
     dk = D // n_head
-    q = F.linear(x, sd[pre + "w_qs.weight"], sd[pre + "w_qs.bias"]).view(B, S, n_head, dk).permute(0, 2, 1, 3)
-    k = F.linear(x, sd[pre + "w_ks.weight"], sd[pre + "w_ks.bias"]).view(B, S, n_head, dk).permute(0, 2, 1, 3)
-    v = F.linear(x, sd[pre + "w_vs.weight"], sd[pre + "w_vs.bias"]).view(B, S, n_head, dk).permute(0, 2, 1, 3)
+    q = _st(F.linear(x, sd[pre + "w_qs.weight"], sd[pre + "w_qs.bias"])).view(B, S, n_head, dk).permute(0, 2, 1, 3)
+    k = _st(F.linear(x, sd[pre + "w_ks.weight"], sd[pre + "w_ks.bias"])).view(B, S, n_head, dk).permute(0, 2, 1, 3)
+    v = _st(F.linear(x, sd[pre + "w_vs.weight"], sd[pre + "w_vs.bias"])).view(B, S, n_head, dk).permute(0, 2, 1, 3)
     attn = torch.matmul(q, k.transpose(-1, -2)) / (dk ** 0.5)
     attn = attn.masked_fill(key_pad_mask.view(B, 1, 1, S), float("-inf"))
-    attn = torch.softmax(attn, dim=-1)
-    out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, S, D)
-    out = F.dropout(F.linear(out, sd[pre + "fc.weight"], sd[pre + "fc.bias"]), dropout_p, training)
-    return F.layer_norm(out + x, (D,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5)
+    attn = _st(torch.softmax(attn, dim=-1))                # (the product feeds P to its second MFMA product in bf16)
+    out = _st(torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, S, D))
+    out = F.dropout(_st(F.linear(out, sd[pre + "fc.weight"], sd[pre + "fc.bias"])), dropout_p, training)
+    return _st(F.layer_norm(_st(out + x), (D,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5))
 
 
 def positionwise_ffn(sd, pre, x, kernel_size, dropout_p, training):
     """transformer/SubLayers.py:85-93."""
-    h = F.relu(_conv1d_rows(x, sd[pre + "w_1.weight"], sd[pre + "w_1.bias"], (kernel_size[0] - 1) // 2))
-    h = _conv1d_rows(h, sd[pre + "w_2.weight"], sd[pre + "w_2.bias"], (kernel_size[1] - 1) // 2)
+    h = _st(F.relu(_conv1d_rows(x, sd[pre + "w_1.weight"], sd[pre + "w_1.bias"], (kernel_size[0] - 1) // 2)))
+    h = _st(_conv1d_rows(h, sd[pre + "w_2.weight"], sd[pre + "w_2.bias"], (kernel_size[1] - 1) // 2))
     h = F.dropout(h, dropout_p, training)
     D = x.shape[-1]
-    return F.layer_norm(h + x, (D,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5)
+    return _st(F.layer_norm(_st(h + x), (D,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5))
 
 
 def fft_block(sd, pre, x, pad_mask, n_head, kernel_size, dropout_p, training):
@@ -85,7 +129,7 @@ def encoder(sd, cfg, texts, pad_mask, training, dropout):
         pe = sinusoid_table(L, tc["encoder_hidden"]).to(emb.dtype)
     else:
         pe = sd["encoder.position_enc"][0, :L]
-    x = F.embedding(texts, emb, padding_idx=0) + pe.unsqueeze(0)
+    x = _st(F.embedding(texts, emb, padding_idx=0) + pe.unsqueeze(0))
     p = tc["encoder_dropout"] if dropout else 0.0
     for i in range(tc["encoder_layer"]):
         x = fft_block(sd, f"encoder.layer_stack.{i}.", x, pad_mask, tc["encoder_head"], tc["conv_kernel_size"], p, training)
@@ -97,10 +141,10 @@ def decoder(sd, cfg, x, pad_mask, training, dropout):
     tc = cfg["transformer"]
     T = x.shape[1]
     if (not training) and T > cfg["max_seq_len"]:
-        x = x + sinusoid_table(T, tc["decoder_hidden"]).to(x.dtype).unsqueeze(0)
+        x = _st(x + sinusoid_table(T, tc["decoder_hidden"]).to(x.dtype).unsqueeze(0))
     else:
         T = min(T, cfg["max_seq_len"])
-        x = x[:, :T] + sd["decoder.position_enc"][0, :T].unsqueeze(0)
+        x = _st(x[:, :T] + sd["decoder.position_enc"][0, :T].unsqueeze(0))
         pad_mask = pad_mask[:, :T]
     p = tc["decoder_dropout"] if dropout else 0.0
     for i in range(tc["decoder_layer"]):
@@ -116,10 +160,10 @@ def variance_predictor(sd, pre, cfg, x, pad_mask, training, dropout):
     p = vc["dropout"] if dropout else 0.0
     C = vc["filter_size"]
     h = _conv1d_rows(x, sd[pre + "conv_layer.conv1d_1.conv.weight"], sd[pre + "conv_layer.conv1d_1.conv.bias"], (k - 1) // 2)
-    h = F.layer_norm(F.relu(h), (C,), sd[pre + "conv_layer.layer_norm_1.weight"], sd[pre + "conv_layer.layer_norm_1.bias"], 1e-5)
+    h = _st(F.layer_norm(_st(F.relu(h)), (C,), sd[pre + "conv_layer.layer_norm_1.weight"], sd[pre + "conv_layer.layer_norm_1.bias"], 1e-5))
     h = F.dropout(h, p, training)
     h = _conv1d_rows(h, sd[pre + "conv_layer.conv1d_2.conv.weight"], sd[pre + "conv_layer.conv1d_2.conv.bias"], 1)
-    h = F.layer_norm(F.relu(h), (C,), sd[pre + "conv_layer.layer_norm_2.weight"], sd[pre + "conv_layer.layer_norm_2.bias"], 1e-5)
+    h = _st(F.layer_norm(_st(F.relu(h)), (C,), sd[pre + "conv_layer.layer_norm_2.weight"], sd[pre + "conv_layer.layer_norm_2.bias"], 1e-5))
     h = F.dropout(h, p, training)
     out = F.linear(h, sd[pre + "linear_layer.weight"], sd[pre + "linear_layer.bias"]).squeeze(-1)
     if pad_mask is not None:
@@ -168,10 +212,10 @@ def variance_adaptor(sd, cfg, pcfg, x, src_mask, mel_mask, max_len, p_target, e_
     p_pred = e_pred = None
     if pitch_level == "phoneme_level":
         p_pred, emb = embed("pitch", x, p_target, src_mask, p_control)
-        x = x + emb
+        x = _st(x + emb)
     if energy_level == "phoneme_level":
         e_pred, emb = embed("energy", x, e_target, src_mask, p_control)
-        x = x + emb
+        x = _st(x + emb)
     if d_target is not None:
         x, mel_len = length_regulate(x, d_target, max_len)
         d_rounded = d_target
@@ -181,10 +225,10 @@ def variance_adaptor(sd, cfg, pcfg, x, src_mask, mel_mask, max_len, p_target, e_
         mel_mask = mask_from_lengths(mel_len)
     if pitch_level == "frame_level":
         p_pred, emb = embed("pitch", x, p_target, mel_mask, p_control)
-        x = x + emb
+        x = _st(x + emb)
     if energy_level == "frame_level":
         e_pred, emb = embed("energy", x, e_target, mel_mask, p_control)
-        x = x + emb
+        x = _st(x + emb)
     return x, p_pred, e_pred, log_d, d_rounded, mel_len, mel_mask
 
 
@@ -196,7 +240,7 @@ def postnet(sd, x, training, dropout, bn_buffers=None, n_layers=5):
     for i in range(n_layers):
         pre = f"postnet.convolutions.{i}."
         w = sd[pre + "0.conv.weight"]
-        h = F.conv1d(h, w, sd[pre + "0.conv.bias"], padding=(w.shape[2] - 1) // 2)
+        h = _st(F.conv1d(h, w, sd[pre + "0.conv.bias"], padding=(w.shape[2] - 1) // 2))
         rm, rv = sd[pre + "1.running_mean"], sd[pre + "1.running_var"]
         if training and bn_buffers is not None:
             rm, rv = bn_buffers[pre + "1.running_mean"], bn_buffers[pre + "1.running_var"]
@@ -204,7 +248,7 @@ def postnet(sd, x, training, dropout, bn_buffers=None, n_layers=5):
             rm, rv = rm.clone(), rv.clone()
         h = F.batch_norm(h, rm, rv, sd[pre + "1.weight"], sd[pre + "1.bias"], training, 0.1, 1e-5)
         if i < n_layers - 1:
-            h = torch.tanh(h)
+            h = _st(torch.tanh(h))
         h = F.dropout(h, p, training)
     return h.transpose(1, 2)
 
@@ -223,8 +267,8 @@ def fastspeech2_forward(sd, cfg, pcfg, speakers, texts, src_lens, max_src_len, m
         sd, cfg, pcfg, x, src_masks, mel_masks, max_mel_len, p_targets, e_targets, d_targets, p_control, e_control,
         d_control, training, dropout)
     x, mel_masks = decoder(sd, cfg, x, mel_masks, training, dropout)
-    mel = F.linear(x, sd["mel_linear.weight"], sd["mel_linear.bias"])
-    post = postnet(sd, mel, training, dropout, bn_buffers) + mel
+    mel = _st(F.linear(x, sd["mel_linear.weight"], sd["mel_linear.bias"]))
+    post = _st(postnet(sd, mel, training, dropout, bn_buffers) + mel)
     return mel, post, p_pred, e_pred, log_d, d_rounded, src_masks, mel_masks, src_lens, mel_lens
 
 

@@ -570,52 +570,59 @@ def full_case_bf16_weights(full_case):
 
 
 def test_full_size_train_step_bf16_per_tensor_budget(dev, full_case, full_case_bf16_weights):
-    """bf16 storage + bf16 MFMA (fp32 accumulate / statistics / master weights) against the fp64 oracle.  Budget: every stored
-    activation carries a relative rounding error <= 2^-9; a gradient tensor sees ~2 x depth such roundings that add in
-    quadrature across independent elements -> per-tensor relative Frobenius error of the order of 2^-9 * sqrt(2 * 8 * 4) ~ 1.6e-2.
-    The step is CHAOTIC at that level: two builds whose LayerNorm kernels agree with each other on all but 1e-5 of their
-    output elements (a different fp32 summation order; both within bf16 rounding of fp64, test_layernorm_production_shape_bf16)
-    produce mel outputs that differ in 73 % of their elements (relative Frobenius 6.9e-3 - the same size as either one's
-    distance to the oracle) and weight gradients that differ from EACH OTHER by 3.6e-3 (median) / 2.5e-2 (max, the PostNet convs:
-    five conv + BatchNorm + tanh layers amplify the mel's rounding noise 4x) - profiles/r02k_dbg_step.log.  A bar against the
-    oracle cannot sit below that realisation-to-realisation spread: measured across seven arithmetic-equivalent builds the
-    PostNet conv weights land between 1.4e-2 and 2.5e-2, everything else below 1.65e-2 (profiles/r02k_bisect*.log; the last
-    decoder layer's query projection reached 1.64e-2 with the log2-domain attention kernels, whose own outputs sit at the same
-    2.3e-3 from fp64 as before).  Bars: 2e-2 for weight tensors, 3.5e-2 for the PostNet's, 6e-2 for the <= 1024-entry vectors
-    (biases, LayerNorm / BatchNorm affine, embedding rows) whose true gradients are sums of cancelling terms."""
+    """bf16 storage + bf16 MFMA (fp32 accumulate / statistics / master weights) at full size, judged against bars DERIVED from
+    bf16 itself and frozen in tests/golden/bf16_bars.json (the round-2 bars were moved four times to sit
+    above the newest measurement; these are not chosen, and are not to be edited without the table changing).
+
+    tests/golden/make_bf16_bars.py runs the fp64 oracle on the network the bf16 engine differentiates (matrices rounded to bf16)
+    twice per seed - exact, and with `oracle.storage(round_st_bf16)`, which rounds every activation the product stores between two
+    kernels (and the gradient flowing back through that edge) to bf16 - over 8 seeded (weights, batch) pairs.  That emulation's own
+    distance to the exact run is what bf16 storage costs by construction: per parameter tensor (relative Frobenius), per output
+    (valid-frame L1), per loss.  Bar of every quantity = 2 x its maximum over the seeds.  The product's distance to the same exact
+    oracle must stay below it - for EVERY tensor by name.  (The step is chaotic at its own rounding level - two
+    arithmetic-equivalent builds differ from each other by about the emulated distance, profiles/r02k_dbg_step.log - which is why
+    the comparison is to a distance, not to the emulation's values.)
+    Against the fp32-master-weight oracle (a slightly different network: the weight rounding adds its share) the numbers are
+    printed for the record only."""
+    import json
+    import os
+    bars = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bars.json")))
+    assert bars["n_seeds"] >= 8 and bars["factor"] == 2.0
     pcfg, mcfg, sd, b, oout, olosses, ograds = full_case
-    _, _, ograds_w = full_case_bf16_weights
+    wout, wlosses, ograds_w = full_case_bf16_weights
     out, losses, grads = _train_step(dev, pcfg, mcfg, sd, b, "bf16")
     assert torch.equal(out[9].cpu(), oout[9])
     valid = (~oout[7]).unsqueeze(-1)
     nval = valid.sum().item() * 80
-    # measured r02b: mel 6.6e-3, post-net mel 3.2e-2 (five k=5 conv + BatchNorm + tanh layers on top of the mel amplify the
-    # bf16 storage rounding of |mel| ~ 5 values: 2^-9 * 5 ~ 1e-2 per stored tensor); bars at ~1.5x the measured values
-    for i, bar in ((0, 1e-2), (1, 5e-2)):
-        l1 = ((out[i].detach().float().cpu().double() - oout[i].detach()).abs() * valid).sum().item() / nval
-        print(f"bf16 full-size valid-frame mel L1 [{i}] = {l1:.3e}")
-        assert l1 <= bar, (i, l1)
-    for a, o in zip(losses, olosses):
-        assert abs(a.item() - o.item()) <= 1e-2 * max(1.0, abs(o.item())), (a.item(), o.item())
-    gmax = max(g.abs().max().item() for g in ograds.values())
     failures = []
-    for tag, ref, bar_w, bar_v in (("vs the fp64 oracle with bf16-rounded weights (activation / gradient storage rounding only)", ograds_w, 2e-2, 6e-2),
-                                   ("vs the fp64 oracle with the fp32 master weights (adds the weight rounding: a different network)", ograds, 5e-2, 1.2e-1)):
-        worst = []
-        for n, og in ref.items():
-            if ograds[n].abs().max().item() < 1e-9 * gmax:   # true gradient zero (w_ks.bias, conv biases in front of BatchNorm): noise only
-                if grads[n].abs().max().item() > 1e-3 * gmax:
-                    failures.append((tag, n, "zero-gradient tensor", grads[n].abs().max().item()))
-                continue
-            fro = ((grads[n] - og).norm() / og.norm()).item()
-            worst.append((fro, n))
-            # weights <= bar_w; vectors of <= 1024 entries (biases, LayerNorm / BatchNorm affine: sums of cancelling terms over
-            # 44 400 rows, their RELATIVE error is the largest) <= bar_v
-            bw = 3.5e-2 if (n.startswith("postnet.") and bar_w < 3e-2) else bar_w
-            if fro > (bar_v if (og.numel() <= 1024 or "emb" in n) else bw):          # (embedding rows: sums over a few tokens)
-                failures.append((tag, n, fro))
-        worst.sort(reverse=True)
-        big = sorted(f for f, n in worst if ref[n].numel() > 1024)
-        print(f"bf16 full-size per-tensor relative Frobenius error {tag}: weight tensors median {big[len(big) // 2]:.2e} max {big[-1]:.2e}; "
-              f"worst 6: {[(f'{f:.2e}', n) for f, n in worst[:6]]}")
+    for i in (0, 1):
+        l1 = ((out[i].detach().float().cpu().double() - wout[i].detach()).abs() * valid).sum().item() / nval
+        print(f"bf16 full-size valid-frame mel L1 [{i}] = {l1:.3e}  (bar {bars['mel_l1']['bar'][i]:.3e} = 2 x emulated {bars['mel_l1']['emulated_max'][i]:.3e})")
+        if l1 > bars["mel_l1"]["bar"][i]:
+            failures.append(("mel_l1", i, l1))
+    for i, (a, o) in enumerate(zip(losses, wlosses)):
+        rel = abs(a.item() - o.item()) / max(1.0, abs(o.item()))
+        if rel > bars["loss_rel"]["bar"][i]:
+            failures.append(("loss", i, rel, bars["loss_rel"]["bar"][i]))
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    worst, ratios = [], []
+    for n, og in ograds_w.items():
+        if ograds[n].abs().max().item() < 1e-9 * gmax:   # true gradient zero (w_ks.bias, conv biases in front of BatchNorm): noise only
+            if grads[n].abs().max().item() > 1e-3 * gmax:
+                failures.append((n, "zero-gradient tensor", grads[n].abs().max().item()))
+            continue
+        fro = ((grads[n] - og).norm() / og.norm()).item()
+        bar = bars["grad"][n]["bar"]
+        worst.append((fro, n))
+        ratios.append((fro / bars["grad"][n]["emulated_max"], n))
+        if fro > bar:
+            failures.append((n, fro, bar))
+    worst.sort(reverse=True)
+    ratios.sort(reverse=True)
+    big = sorted(f for f, n in worst if ograds_w[n].numel() > 1024)
+    print(f"bf16 full-size per-tensor relative Frobenius error vs the fp64 oracle with bf16-rounded weights: weight tensors median "
+          f"{big[len(big) // 2]:.2e} max {big[-1]:.2e}; worst 6: {[(f'{f:.2e}', n) for f, n in worst[:6]]}")
+    print(f"largest product / emulated ratios (bar at 2.0): {[(f'{r:.2f}', n) for r, n in ratios[:8]]}")
+    fm = sorted(((grads[n] - og).norm() / og.norm()).item() for n, og in ograds.items() if og.abs().max().item() >= 1e-9 * gmax and og.numel() > 1024)
+    print(f"for the record, vs the fp32-master-weight oracle (adds the weight rounding): weight tensors median {fm[len(fm) // 2]:.2e} max {fm[-1]:.2e}")
     assert not failures, failures
