@@ -61,6 +61,43 @@ def round_st_bf16(x):
     return _RoundST.apply(x)
 
 
+class _AttnCoreEmu(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dk), key mask) v with the roundings of the product's flash-style kernels (fs2_attn.hip) - used only
+    under `storage(...)`.  Forward: scores and softmax in full precision, P ROUNDED as the operand of the second product.
+    Backward (attn_bwd_dq / attn_bwd_dkv): dV = P_r^T dO;  dP = dO V^T;  delta = rowsum(dO * O) with the STORED (rounded) O - not
+    rowsum(P * dP);  dS = P (dP - delta) ROUNDED as the operand of  dQ = dS_r K / sqrt(dk),  dK = dS_r^T Q / sqrt(dk).
+    q, k, v arrive already rounded (stored tensors); `rnd` is the plain rounding function (no autograd)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, rnd):
+        dk = q.shape[-1]
+        s = torch.matmul(q, k.transpose(-1, -2)) / (dk ** 0.5)
+        s = s.masked_fill(mask, float("-inf"))
+        p = torch.softmax(s, dim=-1)
+        o = rnd(torch.matmul(rnd(p), v))
+        ctx.save_for_backward(q, k, v, p, o)
+        ctx.rnd = rnd
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p, o = ctx.saved_tensors
+        rnd = ctx.rnd
+        dk = q.shape[-1]
+        do = rnd(do)
+        dv = torch.matmul(rnd(p).transpose(-1, -2), do)
+        dp = torch.matmul(do, v.transpose(-1, -2))
+        delta = (do * o).sum(-1, keepdim=True)
+        ds = rnd(p * (dp - delta))
+        dq = torch.matmul(ds, k) / (dk ** 0.5)
+        dkk = torch.matmul(ds.transpose(-1, -2), q) / (dk ** 0.5)
+        return rnd(dq), rnd(dkk), rnd(dv), None, None
+
+
+def _plain_bf16(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
 # ------------------------------------------------------------------------------------------------ helpers
 def sinusoid_table(n_position, d_hid):
     """transformer/Models.py:10-30 — float64 numpy angles, sin on even / cos on odd dims, cast to float32."""
@@ -95,10 +132,13 @@ def multi_head_attention(sd, pre, x, key_pad_mask, n_head, dropout_p, training):
     q = _st(F.linear(x, sd[pre + "w_qs.weight"], sd[pre + "w_qs.bias"])).view(B, S, n_head, dk).permute(0, 2, 1, 3)
     k = _st(F.linear(x, sd[pre + "w_ks.weight"], sd[pre + "w_ks.bias"])).view(B, S, n_head, dk).permute(0, 2, 1, 3)
     v = _st(F.linear(x, sd[pre + "w_vs.weight"], sd[pre + "w_vs.bias"])).view(B, S, n_head, dk).permute(0, 2, 1, 3)
-    attn = torch.matmul(q, k.transpose(-1, -2)) / (dk ** 0.5)
-    attn = attn.masked_fill(key_pad_mask.view(B, 1, 1, S), float("-inf"))
-    attn = _st(torch.softmax(attn, dim=-1))                # (the product feeds P to its second MFMA product in bf16)
-    out = _st(torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, S, D))
+    if _STORE is None:
+        attn = torch.matmul(q, k.transpose(-1, -2)) / (dk ** 0.5)
+        attn = attn.masked_fill(key_pad_mask.view(B, 1, 1, S), float("-inf"))
+        attn = torch.softmax(attn, dim=-1)
+        out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, S, D)
+    else:                                                  # the product's kernel-internal operand roundings made explicit
+        out = _AttnCoreEmu.apply(q, k, v, key_pad_mask.view(B, 1, 1, S), _plain_bf16).permute(0, 2, 1, 3).reshape(B, S, D)
     out = F.dropout(_st(F.linear(out, sd[pre + "fc.weight"], sd[pre + "fc.bias"])), dropout_p, training)
     return _st(F.layer_norm(_st(out + x), (D,), sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5))
 

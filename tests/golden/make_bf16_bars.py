@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 from oracle import fs2_oracle as O  # noqa: E402
 from oracle.weights import seeded_state_dict, synthetic_batch  # noqa: E402
 from tests.golden import configs  # noqa: E402
-from tests.helpers import make_model, oracle_train_case  # noqa: E402
+from tests.helpers import bf16_matrix, make_model, oracle_train_case  # noqa: E402
 
 B, L = 48, 128
 FACTOR = 2.0
@@ -36,7 +36,7 @@ def one(seed):
     model = make_model(pcfg, mcfg, "fp32")
     sd = seeded_state_dict(model.state_dict(), 2025 + 17 * seed)
     b = synthetic_batch(1234 + seed, B, L, dur_lo=4, dur_hi=10, min_len_frac=0.75)
-    sdr = {k: (v.to(torch.bfloat16).to(v.dtype) if (v.is_floating_point() and v.dim() >= 2 and "position_enc" not in k) else v) for k, v in sd.items()}
+    sdr = {k: (v.to(torch.bfloat16).to(v.dtype) if bf16_matrix(k, v) else v) for k, v in sd.items()}
     eo, el, eg, _ = oracle_train_case(pcfg, mcfg, sdr, b, dtype=torch.float64)
     with O.storage(O.round_st_bf16):
         mo, ml, mg, _ = oracle_train_case(pcfg, mcfg, sdr, b, dtype=torch.float64)

@@ -35,6 +35,17 @@ def oracle_train_case(pcfg, mcfg, sd, b, dtype=torch.float32):
     return out, losses, grads, bn_buffers
 
 
+def bf16_matrix(name, v):
+    """the parameters the bf16 engine holds a bf16 copy of and multiplies in bf16: the weights of its MFMA contractions (Linear /
+    Conv1d of the FFT blocks, variance predictors' convs, mel_linear, PostNet convs: Engine._conv_list).  Embedding tables, the
+    variance predictors' 256 -> 1 output rows, biases and normalisation parameters are read in fp32."""
+    if not (v.is_floating_point() and v.dim() >= 2):
+        return False
+    if any(s in name for s in ("position_enc", "emb", "linear_layer")):
+        return False
+    return True
+
+
 def grad_stats(g):
     g = g.double()
     return np.array([g.sum().item(), g.abs().sum().item(), g.norm().item()])

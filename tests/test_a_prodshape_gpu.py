@@ -19,7 +19,7 @@ import torch
 
 from oracle.weights import seeded_state_dict, synthetic_batch
 from tests.golden import configs
-from tests.helpers import make_model, oracle_train_case
+from tests.helpers import bf16_matrix, make_model, oracle_train_case
 
 pytestmark = pytest.mark.gpu
 B, L = 48, 128
@@ -564,7 +564,7 @@ def full_case_bf16_weights(full_case):
     bf16 copies of the fp32 master weights, i.e. it differentiates that slightly different network; against THIS oracle only the
     rounding of stored activations / gradients (and fp32 accumulation) is left."""
     pcfg, mcfg, sd, b, _, _, _ = full_case
-    sdr = {k: (v.to(torch.bfloat16).to(v.dtype) if (v.is_floating_point() and v.dim() >= 2 and "position_enc" not in k) else v) for k, v in sd.items()}
+    sdr = {k: (v.to(torch.bfloat16).to(v.dtype) if bf16_matrix(k, v) else v) for k, v in sd.items()}
     oout, olosses, ograds, _ = oracle_train_case(pcfg, mcfg, sdr, b, dtype=torch.float64)
     return oout, olosses, ograds
 

@@ -5,9 +5,10 @@
 TAG=${1:-r03g}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( time timeout 1500 python -m pytest tests -m gpu -x -q -s ) > gpurun_out/${TAG}_pytest.log 2>&1; grep -E "rel-Frobenius|valid-frame|worst 8|passed|failed" gpurun_out/${TAG}_pytest.log | tail -12
+( time timeout 1500 python -m pytest tests -m gpu -x -q -s ) > gpurun_out/${TAG}_pytest.log 2>&1; grep -E "rel-Frobenius|valid-frame|ratios|passed|failed|FAILED|eager-vs" gpurun_out/${TAG}_pytest.log | tail -16 | cut -c1-900
 timeout 600 python bench.py > gpurun_out/${TAG}_bench_bf16.log 2>&1; tail -1 gpurun_out/${TAG}_bench_bf16.log | cut -c1-2500
 timeout 300 python bench.py --mode synth > gpurun_out/${TAG}_bench_synth.log 2>&1; tail -1 gpurun_out/${TAG}_bench_synth.log | cut -c1-1500
+timeout 300 python bench.py --workload libritts --no-cpu-baseline --no-fp32 --no-synth > gpurun_out/${TAG}_bench_libritts.log 2>&1; tail -1 gpurun_out/${TAG}_bench_libritts.log | cut -c1-700
 for side in 1 0; do
   rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
   timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof -o bench -- python bench.py --steps 6 --warmup 2 --windows 1 --side-stream $side --no-cpu-baseline --no-roofline --no-fp32 --no-synth > gpurun_out/prof.log 2>&1
