@@ -37,8 +37,138 @@ template <int N> __device__ __forceinline__ void w_wait_vm() { asm volatile("s_w
 
 struct WPos { int k, s, mt, nt; };                       // k-th unit of this workgroup (k < 0: none), K-step s of it, its tile
 
-template <int ACT_UNUSED>
-__device__ __forceinline__ void conv_gemm_w_body(const ConvGemmArgs& a, const WSched& sc, unsigned char* smem) {
+// gemm_res_ln (N == 256: a workgroup owns whole rows): the epilogue of the projection IS the LayerNorm kernel
+//   z = dropout(acc + bias) + res  (stored bf16 into Y: saved for backward)    out = mask(LN(z) * gamma + beta)    mean / rstd saved
+// == fs2_conv_gemm followed by fs2_ln_fwd (transformer/SubLayers.py:54-55, 90-93 + Layers.py:25,28) without the projection's
+// output making a round trip through HBM (one bf16 rounding less: y is never stored) and without the second launch.
+struct WLn {
+    const float* gamma; const float* beta;   // gamma == null: plain contraction
+    void* out; long ldo;
+    float* mean; float* rstd;
+    float eps, p_pre;
+    uint64_t seed_pre;
+    const uint64_t* seed_dev;
+};
+
+// Layout after the half-wave swaps: lane (fl, fh) of wave (wm, wn) holds, for its two rows m = m0 + 64 wm + 32 mb + fl, the
+// columns 128 wn + 32 nb + 16 ch + 8 fh + [0, 8) as v[mb][nb][8 ch + e].  A row is spread over the lane pair (fh = 0, 1) and the
+// wave pair (wn = 0, 1): row sums = lane sum + one cross-half shuffle + one exchange through LDS (red: [2][8 waves][64 rows]).
+__device__ __forceinline__ void w_epilogue_resln(const ConvGemmArgs& a, const WLn& ln, f32x16 (&acc)[2][4], int m0, int wave, int wm, int wn,
+                                                 int fl, int fh, const int32_t* lens_s, float* red) {
+    bf16_t* Z = reinterpret_cast<bf16_t*>(a.Y);
+    bf16_t* O = reinterpret_cast<bf16_t*>(ln.out);
+    const bf16_t* R = reinterpret_cast<const bf16_t*>(a.R);
+    const uint64_t seed = ln.seed_pre + (ln.seed_dev ? *ln.seed_dev : 0ull);
+    const float ik = ln.p_pre > 0.f ? 1.f / (1.f - ln.p_pre) : 1.f;
+    float rsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + wm * 64 + mb * 32 + fl;
+        const bool rowok = m < a.M;
+        const int mc = rowok ? m : a.M - 1;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][e]), __float_as_uint(acc[mb][nb][4 + e]), false, false);
+                u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][nb][8 + e]), __float_as_uint(acc[mb][nb][12 + e]), false, false);
+                v[e] = __uint_as_float(s0[0]); v[4 + e] = __uint_as_float(s0[1]);
+                v[8 + e] = __uint_as_float(s1[0]); v[12 + e] = __uint_as_float(s1[1]);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int n = wn * 128 + nb * 32 + ch * 16 + fh * 8;
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = v[ch * 8 + e];
+                if (a.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n), b1 = *reinterpret_cast<const float4*>(a.bias + n + 4);
+                    x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+                }
+                if (ln.p_pre > 0.f) {
+                    const uint32_t e0 = (uint32_t)m * 256u + (uint32_t)n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] *= fs2_drop_scale(seed, e0 + e, ln.p_pre, ik);
+                }
+                if (R) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(R + (size_t)mc * a.ldr + n);
+                    const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[2 * e] += __uint_as_float(u[e] << 16); x[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+                }
+                uint4 zq;
+                uint32_t* zu = reinterpret_cast<uint32_t*>(&zq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zu[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
+                if (rowok) *reinterpret_cast<uint4*>(Z + (size_t)m * a.ldy + n) = zq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {            // statistics on the values as stored: backward sees the same z
+                    const float lo = __uint_as_float(zu[e] << 16), hi = __uint_as_float(zu[e] & 0xffff0000u);
+                    acc[mb][nb][ch * 8 + 2 * e] = lo; acc[mb][nb][ch * 8 + 2 * e + 1] = hi;
+                    rsum[mb] += lo + hi;
+                }
+            }
+        }
+    }
+    // ---- row means: lane pair, then wave pair through LDS
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        rsum[mb] += __shfl_xor(rsum[mb], 32, 64);
+        if (fh == 0) red[wave * 64 + mb * 32 + fl] = rsum[mb];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) mean[mb] = (rsum[mb] + red[(wave ^ 1) * 64 + mb * 32 + fl]) * (1.f / 256.f);
+    float rsq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc[mb][nb][r] - mean[mb]; rsq[mb] += d * d; }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        rsq[mb] += __shfl_xor(rsq[mb], 32, 64);
+        if (fh == 0) red[512 + wave * 64 + mb * 32 + fl] = rsq[mb];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) rstd[mb] = rsqrtf((rsq[mb] + red[512 + (wave ^ 1) * 64 + mb * 32 + fl]) * (1.f / 256.f) + ln.eps);
+    // ---- normalise, scale, mask, store
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + wm * 64 + mb * 32 + fl;
+        if (m >= a.M) continue;
+        bool padrow = false;
+        if (a.lens) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
+        if (wn == 0 && fh == 0) { ln.mean[m] = mean[mb]; ln.rstd[m] = rstd[mb]; }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int n = wn * 128 + nb * 32 + ch * 16 + fh * 8;
+                const float4 g0 = *reinterpret_cast<const float4*>(ln.gamma + n), g1 = *reinterpret_cast<const float4*>(ln.gamma + n + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(ln.beta + n), b1 = *reinterpret_cast<const float4*>(ln.beta + n + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = padrow ? 0.f : (acc[mb][nb][ch * 8 + e] - mean[mb]) * rstd[mb] * gm[e] + bt[e];
+                uint4 oq;
+                uint32_t* ou = reinterpret_cast<uint32_t*>(&oq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+                *reinterpret_cast<uint4*>(O + (size_t)m * ln.ldo + n) = oq;
+            }
+    }
+}
+
+template <bool RESLN>
+__device__ __forceinline__ void conv_gemm_w_body(const ConvGemmArgs& a, const WSched& sc, const WLn& ln, unsigned char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;             // wave tile: rows 64 wm .., columns 128 wn ..
@@ -65,8 +195,16 @@ __device__ __forceinline__ void conv_gemm_w_body(const ConvGemmArgs& a, const WS
             const int m0 = sc.tmap[1 + n_real + p] * 256;
             for (int i = tid; i < 256 * cpr; i += 512) {
                 const int m = m0 + i / cpr, n = (i % cpr) * 8;
-                if (m < a.M) *reinterpret_cast<uint4*>(Y + (size_t)m * a.ldy + n) = make_uint4(0, 0, 0, 0);
+                if (m < a.M) {
+                    *reinterpret_cast<uint4*>(Y + (size_t)m * a.ldy + n) = make_uint4(0, 0, 0, 0);
+                    if (RESLN) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(ln.out) + (size_t)m * ln.ldo + n) = make_uint4(0, 0, 0, 0);
+                }
             }
+            // (gemm_res_ln: FINITE statistics for the rows nobody normalises - LayerNorm's backward multiplies them by a zero
+            // gradient, and 0 x whatever torch.empty left there would put NaNs into padded rows that the k = 9 data gradient reads)
+            if (RESLN)
+                for (int i = tid; i < 256; i += 512)
+                    if (m0 + i < a.M) { ln.mean[m0 + i] = 0.f; ln.rstd[m0 + i] = 0.f; }
         }
     }
     __syncthreads();                                                         // lens staged (read in the epilogues)
@@ -170,7 +308,11 @@ __device__ __forceinline__ void conv_gemm_w_body(const ConvGemmArgs& a, const WS
         if (nxt.k >= 0) issue(nxt, (buf + 3) & 3);
         kstep(buf);
         if (q[0].s == nk - 1) {                                              // the tile's last K-step: registers -> bf16 rows
-            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, q[0].mt * 256, q[0].nt * 256 + wn * 128, wm, fl, fh, lens_s, bias_s, lane)));
+            if (RESLN) {
+                w_epilogue_resln(a, ln, acc, q[0].mt * 256, wave, wm, wn, fl, fh, lens_s, reinterpret_cast<float*>(smem + W_AUX + W_MAXB * 4));
+            } else {
+                FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, q[0].mt * 256, q[0].nt * 256 + wn * 128, wm, fl, fh, lens_s, bias_s, lane)));
+            }
             zero_acc();
         }
         q[0] = q[1]; q[1] = q[2]; q[2] = nxt;
@@ -178,9 +320,10 @@ __device__ __forceinline__ void conv_gemm_w_body(const ConvGemmArgs& a, const WS
     }
 }
 
-__global__ void __launch_bounds__(512, 2) conv_gemm_w_kernel(ConvGemmArgs a, WSched sc) {
+template <bool RESLN>
+__global__ void __launch_bounds__(512, 2) conv_gemm_w_kernel(ConvGemmArgs a, WSched sc, WLn ln) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    conv_gemm_w_body<0>(a, sc, smem);
+    conv_gemm_w_body<RESLN>(a, sc, ln, smem);
 }
 
 static int w_cu_count() {
@@ -207,9 +350,12 @@ bool fs2_conv_gemm_w_ok(const ConvGemmArgs& a, bool has_map, int dtype) {
     return tiles >= 96;                                       // fewer: the 128^2 / persistent kernels fill more CUs
 }
 
-void fs2_conv_gemm_w_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream) {
+static void w_launch(const ConvGemmArgs& a, const int32_t* tile_map, const WLn& ln, hipStream_t stream) {
     static Fs2DevOnce once;
-    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS); });
+    once.run([&] {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    });
     WSched sc;
     sc.ntm = fs2_cdiv(a.M, 256);
     sc.ntn = a.N / 256;
@@ -218,5 +364,39 @@ void fs2_conv_gemm_w_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     const long tiles = (long)sc.ntm * sc.ntn;
     if (tiles < G) G = (int)((tiles + 7) & ~7L);
     sc.G = G;
-    conv_gemm_w_kernel<<<(unsigned)G, 512, W_LDS, stream>>>(a, sc);
+    if (ln.gamma) conv_gemm_w_kernel<true><<<(unsigned)G, 512, W_LDS, stream>>>(a, sc, ln);
+    else conv_gemm_w_kernel<false><<<(unsigned)G, 512, W_LDS, stream>>>(a, sc, ln);
+}
+
+void fs2_conv_gemm_w_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipStream_t stream) {
+    WLn ln = {};
+    w_launch(a, tile_map, ln, stream);
+}
+
+// ---- gemm_res_ln: Linear (N = 256) + dropout + residual + LayerNorm + pad-row zero in one launch (SURVEY §8(b) export list)
+extern "C" int fs2_gemm_res_ln_supported(int M, int N, int Cin, int S, int dtype) {
+    if (dtype != FS2_BF16 || N != 256 || Cin % 32 != 0 || Cin < 128 || M <= 0 || S <= 0 || M % S != 0) return 0;
+    if ((double)M * Cin * 2 >= 4.0e9 || M / S > W_MAXB) return 0;
+    return fs2_cdiv(M, 256) >= 16 ? 1 : 0;                // fewer tiles: the separate small-tile kernels keep more CUs busy
+}
+
+extern "C" int fs2_gemm_res_ln_fwd(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Z, long ldz,
+                                   void* out, long ldo, const float* gamma, const float* beta, float* mean, float* rstd, const int32_t* lens,
+                                   const int32_t* tile_map, int M, int N, int Cin, int S, float eps, float p_pre, uint64_t seed_pre,
+                                   const uint64_t* seed_dev, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(X && Wpacked && Z && out && gamma && beta && mean && rstd, "gemm_res_ln: null pointer");
+    FS2_CHECK_ARG(fs2_gemm_res_ln_supported(M, N, Cin, S, dtype), "gemm_res_ln: unsupported shape M=%d N=%d Cin=%d S=%d dtype=%d", M, N, Cin, S, dtype);
+    FS2_CHECK_ARG(ldx % 8 == 0 && ldz % 8 == 0 && ldo % 8 == 0 && (!R || ldr % 8 == 0) && p_pre >= 0.f && p_pre < 1.f, "gemm_res_ln: bad strides / p");
+    FS2_CHECK_ARG((((uintptr_t)X | (uintptr_t)Wpacked | (uintptr_t)Z | (uintptr_t)out | (uintptr_t)R | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)bias) & 15) == 0,
+                  "gemm_res_ln: operands must be 16-byte aligned");
+    ConvGemmArgs a = {};
+    a.X = X; a.ldx = ldx; a.W = Wpacked; a.ldw = Cin; a.bias = bias; a.R = R; a.ldr = ldr; a.Y = Z; a.ldy = ldz; a.lens = lens;
+    a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = 1; a.dil = 1; a.pad = 0; a.act = FS2_ACT_NONE; a.slope = 0.f; a.in_act = FS2_ACT_NONE;
+    a.in_slope = 0.f; a.accumulate = 0; a.out_scale = 1.f; a.vec_ok = 1; a.dbg = 0;
+    WLn ln;
+    ln.gamma = gamma; ln.beta = beta; ln.out = out; ln.ldo = ldo; ln.mean = mean; ln.rstd = rstd; ln.eps = eps; ln.p_pre = p_pre;
+    ln.seed_pre = seed_pre; ln.seed_dev = seed_dev;
+    w_launch(a, tile_map, ln, stream);
+    FS2_CHECK_LAUNCH("gemm_res_ln");
+    return FS2_OK;
 }

@@ -67,6 +67,7 @@ class Engine:
         self._side_keep = []
         self._ln_pending = []
         self.defer_ln_reduce = True
+        self.fuse_proj_ln = False       # see _proj_ln: the one-launch form is measured slower at the bench shape
         self._pack_pending = False
         self._bn_ws = {}
         self._bn_eval = {}
@@ -265,6 +266,23 @@ class Engine:
         return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res, tmap=self._tmap(lens),
                              tail_ws=self._tail_workspace(x.device))
 
+    def _proj_ln(self, W, key, x, res, ln, lens, B, S, p, site, seed_dev):
+        """N = 256 projection -> dropout -> + residual -> LayerNorm.  Returns (z, out, mean, rstd) with z = what ln_bwd needs.
+        `fuse_proj_ln` runs it as ONE launch (fs2_gemm_res_ln_fwd: the pre-norm tensor makes one HBM trip instead of three);
+        measured on the step it is SLOWER than the two launches (8.90 vs 8.68 ms, profiles/r03k_ab_env.log, r03l_ab_env.log:
+        the 256-row x full-width tile leaves 174 workgroups for 256 CUs and the row statistics serialise the epilogue), so the
+        default stays two launches; the fused operator stays in the library, parity-tested, for shapes with more rows."""
+        gamma, beta = self.P[ln + "weight"], self.P[ln + "bias"]
+        kw = _seed_kw("seed_pre", site, seed_dev)
+        if self.fuse_proj_ln and lens is not None:
+            wf, _, b, _ = W[key]
+            r = ops.gemm_res_ln(x, wf, b, res, gamma, beta, lens, self._tmap(lens), B, S, p_pre=p, **kw)
+            if r is not None:
+                return r
+        y = self._gemm(W, key, x, S, lens=lens)
+        out, mean, rstd = ops.ln_fwd(y, res, gamma, beta, lens, B, S, p_pre=p, **kw)
+        return y, out, mean, rstd
+
     def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None, lens=None):
         """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
         _, wd, _, shape = W[key]
@@ -387,14 +405,15 @@ class Engine:
         # padded rows are never consumed downstream (keys masked, LN output re-masked): their tiles are skipped
         qkv = self._gemm(W, a + "qkv", x, S, lens=lens)
         ctx, lse = ops.attn_fwd(qkv, lens, B, S, n_head, self.d // n_head)
-        y1 = self._gemm(W, a + "fc", ctx, S, lens=lens)
-        h, mean1, rstd1 = ops.ln_fwd(y1, x, self.P[a + "layer_norm.weight"], self.P[a + "layer_norm.bias"], lens, B, S,
-                                     p_pre=p, **_seed_kw("seed_pre", site, seed_dev))
+        y1, h, mean1, rstd1 = self._proj_ln(W, a + "fc", ctx, x, a + "layer_norm.", lens, B, S, p, site, seed_dev)
         hid = self._gemm(W, f + "w_1", h, S, taps=ks[0], pad=(ks[0] - 1) // 2, act=ACT_RELU,
                          lens=lens if ks[1] == 1 else None)
-        y2 = self._gemm(W, f + "w_2", hid, S, taps=ks[1], pad=(ks[1] - 1) // 2, lens=lens if ks[1] == 1 else None)
-        out, mean2, rstd2 = ops.ln_fwd(y2, h, self.P[f + "layer_norm.weight"], self.P[f + "layer_norm.bias"], lens, B, S,
-                                       p_pre=p, **_seed_kw("seed_pre", site + 1, seed_dev))
+        if ks[1] == 1:
+            y2, out, mean2, rstd2 = self._proj_ln(W, f + "w_2", hid, h, f + "layer_norm.", lens, B, S, p, site + 1, seed_dev)
+        else:
+            y2 = self._gemm(W, f + "w_2", hid, S, taps=ks[1], pad=(ks[1] - 1) // 2)
+            out, mean2, rstd2 = ops.ln_fwd(y2, h, self.P[f + "layer_norm.weight"], self.P[f + "layer_norm.bias"], lens, B, S,
+                                           p_pre=p, **_seed_kw("seed_pre", site + 1, seed_dev))
         if keep:
             sv.x, sv.qkv, sv.ctx, sv.lse, sv.z1, sv.mean1, sv.rstd1 = x, qkv, ctx, lse, y1, mean1, rstd1
             sv.h, sv.hid, sv.z2, sv.mean2, sv.rstd2 = h, hid, y2, mean2, rstd2

@@ -242,6 +242,30 @@ def ln_fwd(y, res, gamma, beta, lens, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, p_p
     return out, mean, rstd
 
 
+def gemm_res_ln(x, wpacked, bias, res, gamma, beta, lens, tmap, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, seed_dev=None):
+    """Linear (N = 256) + dropout + residual + LayerNorm + pad-row zero in ONE launch (fs2_gemm_res_ln_fwd).  Returns
+    (z, out, mean, rstd) exactly like conv_gemm followed by ln_fwd (z is what ln_fwd leaves in its y argument), or None when the
+    shape is not supported (the caller then runs the two launches)."""
+    M, Cin = x.shape
+    N = wpacked.shape[0]
+    if x.dtype != torch.bfloat16 or wpacked.shape[1] != 1 or not _lib.load().fs2_gemm_res_ln_supported(M, N, Cin, S, BF16):
+        return None
+    z = torch.empty(M, N, device=x.device, dtype=x.dtype)
+    out = torch.empty(M, N, device=x.device, dtype=x.dtype)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("fs2_gemm_res_ln_fwd", _p(x), x.stride(0), _p(wpacked), _p(bias), _p(res), res.stride(0) if res is not None else 0, _p(z), N,
+              _p(out), N, _p(gamma), _p(beta), _p(mean), _p(rstd), _p(lens), _p(tmap), M, N, Cin, S, eps, p_pre, seed_pre, _p(seed_dev), BF16,
+              _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin, e0, e1, 7, lens is not None, S))
+    return z, out, mean, rstd
+
+
 def ln_bwd(z, dout, gamma, lens, mean, rstd, dgamma, dbeta, B, S, want_d1=True, want_d2=False, d1_add=None, p_pre=0.0,
            seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False, seed_dev=None, defer=False):
     """defer=True: the affine-gradient reduction is NOT launched; returns (d1, d2, ws) and the caller runs

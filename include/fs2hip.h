@@ -123,6 +123,16 @@ int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, const float
 int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, const int32_t* lens, void* out,
                float* mean, float* rstd, int B, int S, int C, float eps, float p_pre, uint64_t seed_pre, float p_post,
                uint64_t seed_post, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
+/* gemm_res_ln: the N = 256 projection of a transformer sub-layer AND its LayerNorm in one launch (SubLayers.py:54-55, 90-93 +
+ * Layers.py:25,28): Z = dropout_pre(X W^T + bias) + R (bf16, saved for backward: what fs2_ln_fwd leaves in y),
+ * out = mask(LN(Z) * gamma + beta), mean / rstd saved.  Same dropout stream and statistics as fs2_conv_gemm + fs2_ln_fwd; the
+ * projection's output is never stored (one bf16 rounding less).  bf16, N == 256, Cin % 32 == 0; fs2_gemm_res_ln_supported
+ * returns 1 / 0 (a flag, not a status) - otherwise call the two entry points. */
+int fs2_gemm_res_ln_supported(int M, int N, int Cin, int S, int dtype);
+int fs2_gemm_res_ln_fwd(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Z, long ldz,
+                        void* out, long ldo, const float* gamma, const float* beta, float* mean, float* rstd, const int32_t* lens,
+                        const int32_t* tile_map, int M, int N, int Cin, int S, float eps, float p_pre, uint64_t seed_pre,
+                        const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 /* d1 = dz (+ d1_add), d2 = dz * dropmask_pre * (relu_bwd ? z>0 : 1); dgamma/dbeta += column sums.
  * partial_ws: caller workspace of per-block partial sums, reduced by a 2nd launch: FS2_LN_BWD_GRID*2*C floats when dgamma /
  * dbeta are given (nothing is written beyond that).  dgamma = dbeta = NULL DEFERS the reduction: the workspace must then hold

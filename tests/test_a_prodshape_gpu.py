@@ -338,6 +338,56 @@ def test_hifigan_bf16_per_stage_budget(dev):
     assert pw <= 2 * ew, (pw, ew)
 
 
+@pytest.mark.parametrize("name,K,S", [("fc", 256, 925), ("w_2", 1024, 925), ("fc enc", 256, 128)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_gemm_res_ln_matches_contraction_plus_layernorm(dev, name, K, S, p):
+    """fs2_gemm_res_ln_fwd (the wide one-tap kernel with the LayerNorm epilogue) at the FFT blocks' production shapes, ragged lens +
+    tile map, dropout on and off: the saved pre-norm sum z against an exact-product reference with the SAME dropout mask (read off
+    fs2_ln_fwd's own stream: final bf16 rounding only), the statistics and the normalised output against fp64 LayerNorm of the
+    product's stored z, padded rows exactly zero."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(ord(c) for c in name) + int(p * 10))
+    M, N = B * S, 256
+    lens = ragged_lens(S, seed=21).to(dev)
+    tmap = ops.tile_map(lens, B, S)
+    x = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(N, 1, K, generator=g) / math.sqrt(K)).to(dev).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev).to(torch.bfloat16)
+    gamma = (torch.rand(N, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(N, generator=g) * 0.1).to(dev)
+    seed = 0x1234567 + 77
+    r = ops.gemm_res_ln(x, w, bias, res, gamma, beta, lens, tmap, B, S, p_pre=p, seed_pre=seed)
+    assert r is not None, "shape not taken by the fused kernel"
+    z, out, mean, rstd = r
+    # the dropout mask of this (seed, element) stream: fs2_ln_fwd on ones
+    ones = torch.ones(M, N, device=dev, dtype=torch.bfloat16)
+    ops.ln_fwd(ones, None, gamma, beta, None, B, S, p_pre=p, seed_pre=seed)            # ones <- drop(ones) (z written back in place)
+    mask = ones.double() if p > 0 else torch.ones(M, N, device=dev, dtype=torch.float64)
+    if p > 0:
+        keep = (mask != 0).double().mean().item()
+        assert abs(keep - (1 - p)) < 5e-3 and torch.allclose(mask[mask != 0], torch.tensor(1.25, dtype=torch.float64, device=dev))
+    y = conv_ref_gpu(x, w, bias, S, 0)
+    pad = (torch.arange(S, device=dev).unsqueeze(0) >= lens.unsqueeze(1)).reshape(-1)
+    # (z at padded rows is unspecified - zero in fully padded tiles - and never used: LayerNorm's backward zeroes those rows)
+    assert_rounding_only(z[~pad], (y * mask + res.double())[~pad], torch.bfloat16, (name, p, "z"))
+    assert torch.isfinite(z.float()).all() and torch.isfinite(mean).all() and torch.isfinite(rstd).all()
+    zd = z.double()
+    mu = zd.mean(1, keepdim=True)
+    var = ((zd - mu) ** 2).mean(1, keepdim=True)
+    rs = (var + 1e-5).rsqrt()
+    assert torch.allclose(mean.double()[~pad], mu.squeeze(1)[~pad], rtol=0, atol=2e-5) and torch.allclose(rstd.double()[~pad], rs.squeeze(1)[~pad], rtol=2e-5, atol=0)
+    ref = (zd - mu) * rs * gamma.double() + beta.double()
+    ref[pad] = 0
+    assert_rounding_only(out, ref, torch.bfloat16, (name, p, "out"))
+    assert (out[pad] == 0).all()
+    # and against the two-launch path on the same inputs: identical statistics up to the one rounding the fused form saves
+    y2 = ops.conv_gemm(x, w, bias, S, lens=lens, tmap=tmap)
+    out2, mean2, rstd2 = ops.ln_fwd(y2, res, gamma, beta, lens, B, S, p_pre=p, seed_pre=seed)
+    valid = ~pad
+    assert ((out.float() - out2.float())[valid].abs().max().item()) <= 0.1 and ((out.float() - out2.float())[valid].norm() / out2.float()[valid].norm()).item() < 6e-3
+
+
 @pytest.mark.parametrize("ks", [2, 4])
 def test_splitk_contraction_matches_unsplit_reference(dev, ks):
     """the encoder's k=9 data gradient shape (M = 48 x 128, N = 256, K = 9 x 1024) through the K-split path: partial tiles stored

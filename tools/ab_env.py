@@ -22,6 +22,10 @@ def one():
     if os.environ.get("AB_SKIP_WGRAD") == "1":              # the critical chain alone (weight gradients not computed at all)
         from fastspeech2_amd import ops
         ops.conv_wgrad = lambda *a, **k: None
+    if os.environ.get("AB_FUSE_LN") == "1":
+        model._engine.fuse_proj_ln = True
+    if os.environ.get("AB_WGRAD_LATE") == "0":
+        model._engine.wgrad_after_dgrad = False
     if os.environ.get("AB_SIDE") == "0":
         model._engine.use_side_stream = False
     # (stream priorities: torch.cuda.Stream.priority_range() is (0, -1) on this stack - the step runs on -1, the side stream on 0;
