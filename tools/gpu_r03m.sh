@@ -1,0 +1,4 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 900 python tools/ab_env.py "" FS2_ATTN_PP=0 > gpurun_out/r03m_ab_env.log 2>&1; cat gpurun_out/r03m_ab_env.log
