@@ -211,7 +211,7 @@ __device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* row, int
 
 __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
                                                                long ldo, float* __restrict__ lse,
-                                                               const int32_t* __restrict__ lens, int S, int H, float scale, int abl) {
+                                                               const int32_t* __restrict__ lens, int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
     __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
-        const bool more = (k0 + 64 < len) && !abl;
+        const bool more = k0 + 64 < len;
         if (more) {                                       // next tile travels while this one is multiplied
             TILE_LOAD_REGS(tk, K, ld, k0 + 64, S - 1);
             TILE_LOAD_REGS(tv, V, ld, k0 + 64, S - 1);
@@ -635,289 +635,6 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
     }
 }
 
-// ================================================================== ping-pong kernels (bf16, S >= 256)
-// r03m: the kernels above spend ~1000 MFMA cycles and ~1500 VALU cycles per wave and key tile, and the two co-resident waves of a
-// SIMD (from two independent workgroups, each barrier-synchronised with its own three siblings) do not overlap them: a tile step
-// takes about the SUM (no-load ablation: 53 of 66 us remain when the in-loop tile loads are removed - it is not the staging).
-// Here a workgroup is 8 waves = one 256-query block, the two waves of a SIMD belong to the SAME workgroup and run a tile step in
-// OPPOSITE phases, held there by one workgroup barrier per phase: while wave w multiplies (P V of the previous tile, then Q K^T
-// of the current one: 32 MFMAs) wave w+4 runs the current tile's softmax on the VALU, then they swap.  K/V tiles arrive by
-// LDS-DMA (swizzle on the source address) into a 4-slot ring two tiles ahead of their first use: no prefetch registers, no
-// ds_write pass, no address arithmetic in the loop beyond one clamp per piece.
-typedef unsigned fs2_u32x2 __attribute__((ext_vector_type(2)));
-static constexpr int AR_D = 4, AR_TILE = 64 * 256, AR_SLOT = 2 * AR_TILE;
-template <int N> __device__ __forceinline__ void ar_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-__device__ __forceinline__ void ar_glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned ar_lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
-
-// the per-wave state of the forward kernel and its three pieces of work; G (0 | 1) = the phase group: group 0 multiplies in the
-// even barrier phases and runs the softmax in the odd ones, group 1 the other way round
-struct FwdPP {
-    bf16x8 qf[8], pa[4];
-    f32x16 o[4], s[2];
-    float m, l;
-};
-// The multiply phase of one tile step: O^T += V(t-1)^T P(t-1)^T (16 MFMAs; the accumulators are kept TRANSPOSED - lane = query,
-// registers = head columns - so that the running-maximum rescale and the final 1/l are per-lane multiplies and the epilogue
-// stores 16-byte row pieces), then S^T(t) = K(t) Q^T (16 MFMAs).  One LDS fragment feeds one MFMA.
-// r03m, measured on the first two builds of this kernel: a wave issues about one instruction per 5 cycles, so everything
-// between two MFMAs (32 cycles) has to fit in ~5 issues.  With swizzled addresses formed per read (~10 VALU each) a 16-MFMA
-// product took ~1400 cycles whatever the read look-ahead (one step or a window of six).  Hence: the sixteen lane-dependent
-// address parts live in registers as ABSOLUTE LDS addresses of the current ring slot (aK: K fragment of d-slice st; aV: the two
-// transposing reads of head-column block nb), every other term is an instruction immediate, and the whole set moves to the next
-// slot with one add per register and tile.
-typedef const __attribute__((address_space(3))) uint4* lds_u4p;
-template <bool PV, bool QK>
-__device__ __forceinline__ void fwd_pp_mfma(FwdPP& z, const unsigned (&aV)[8], const unsigned (&aK)[8]) {
-    constexpr int W = 8, N0 = PV ? 16 : 0, N = N0 + (QK ? 16 : 0);
-    bf16x8 f[N];
-    auto load = [&](int i) -> bf16x8 {
-        if (i < N0) {
-            const int gk = i >> 2, nb = i & 3;
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(aV[2 * nb] + gk * 4096));
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(aV[2 * nb + 1] + gk * 4096));
-            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-        const int j = i - N0;
-        return __builtin_bit_cast(bf16x8, *(lds_u4p)(size_t)(aK[j >> 1] + (j & 1) * 8192));
-    };
-    if (QK) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z.s[kb][r] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < W; ++i) f[i] = load(i);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (i < N0) z.o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], z.pa[i >> 2], z.o[i & 3], 0, 0, 0);
-        else z.s[(i - N0) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], z.qf[(i - N0) >> 1], z.s[(i - N0) & 1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + W < N) f[i + W] = load(i + W);
-    }
-}
-// softmax of one 64-key tile in the log2 domain with the lazy running maximum of attn_fwd_bf16_kernel; leaves P packed in z.pa
-__device__ __forceinline__ void fwd_pp_softmax(FwdPP& z, int k0, int len, float sc2, int h2) {
-    if (k0 + 64 > len) {                                     // (one per-lane threshold against compile-time row constants)
-        int thr = len - k0 - 4 * h2;
-        asm volatile("" : "+v"(thr));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kb * 32 + (r & 3) + 8 * (r >> 2) >= thr) z.s[kb][r] = -INFINITY;
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, z.s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc2;
-    if (__builtin_amdgcn_ballot_w64(mx > z.m + 8.f) != 0ull) {
-        const float mn = fmaxf(z.m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(z.m - mn);
-        z.l *= alpha;
-        z.m = mn;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z.o[nb][r] *= alpha;  // (transposed accumulators: this lane's query)
-    }
-    float rs0 = 0.f, rs1 = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            z.s[kb][r] = __builtin_amdgcn_exp2f(fmaf(z.s[kb][r], sc2, -z.m));
-            z.s[kb][r + 1] = __builtin_amdgcn_exp2f(fmaf(z.s[kb][r + 1], sc2, -z.m));
-            rs0 += z.s[kb][r]; rs1 += z.s[kb][r + 1];
-        }
-    float rs = rs0 + rs1;
-    rs += __shfl_xor(rs, 32, 64);
-    z.l += rs;
-#pragma unroll
-    for (int gk = 0; gk < 4; ++gk) {
-        float pv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pv[e] = z.s[gk >> 1][8 * (gk & 1) + e];
-        z.pa[gk] = pack8(pv);
-    }
-}
-
-__global__ void __launch_bounds__(512) attn_fwd_pp_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx, long ldo,
-                                                          float* __restrict__ lse, const int32_t* __restrict__ lens, int S, int H,
-                                                          float scale, unsigned long long* dbg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // AR_D x (K tile | V tile)
-    const int tid = threadIdx.x, lane = tid & 63, fl = lane & 31, h2 = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = w >> 2;                             // phase group: waves w and w + 4 sit on the same SIMD
-    const int rb = 2 * (w & 3) + g;               // the wave's 32-query block: both groups get blocks of a partial tile
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int len = lens ? min(lens[b], S) : S;
-    const int q0 = qt * 256;
-    const size_t rowbase = (size_t)b * S;
-    bf16_t* out = ctx + rowbase * ldo + h * DK;
-    float* lse_o = lse + ((size_t)b * H + h) * S;
-    if (q0 >= len) {
-        for (int i = tid; i < 256 * 32; i += 512) {
-            int r = i >> 5, c = (i & 31) * 4;
-            if (q0 + r < S) st4<bf16_t>(out + (size_t)(q0 + r) * ldo + c, make_float4(0.f, 0.f, 0.f, 0.f));
-        }
-        if (tid < 256 && q0 + tid < S) lse_o[q0 + tid] = 0.f;
-        return;
-    }
-    const bf16_t* Q = qkv + rowbase * ld + h * DK;
-    const unsigned char* Kb = reinterpret_cast<const unsigned char*>(qkv + rowbase * ld + (size_t)H * DK + h * DK);
-    const unsigned char* Vb = reinterpret_cast<const unsigned char*>(qkv + rowbase * ld + (size_t)2 * H * DK + h * DK);
-#ifdef FS2_DEV          // per-wave time stamps of workgroup (0, 0, 0) for tools/bench_attn.py (the product build has none of it)
-#define AT_STAMP(i) do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (i) < 64) dbg[w * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define AT_STAMP(i) do { } while (0)
-#endif
-    AT_STAMP(0);
-    const int nt = (len + 63) >> 6;
-    const unsigned smem_u = ar_lds_addr(smem);
-    // ---- this wave's DMA pieces: tile rows 8w .. 8w+7 of K and of V (a piece = 4 rows x 256 B, lane-linear in LDS)
-    const unsigned ldb = (unsigned)(ld * 2);
-    const int prow = 8 * w + (lane >> 4);
-    const unsigned pcol0 = (unsigned)(((lane & 15) ^ (((prow & 3) << 2) | ((prow >> 2) & 3))) << 4);
-    const unsigned pcol1 = (unsigned)(((lane & 15) ^ ((((prow + 4) & 3) << 2) | (((prow + 4) >> 2) & 3))) << 4);
-    auto issue = [&](int t) {
-        const unsigned dst = smem_u + (unsigned)((t & (AR_D - 1)) * AR_SLOT + 2 * w * 1024);
-        const unsigned v0 = (unsigned)min(t * 64 + prow, S - 1) * ldb + pcol0;
-        const unsigned v1 = (unsigned)min(t * 64 + prow + 4, S - 1) * ldb + pcol1;
-        ar_glds16(v0, Kb, dst);
-        ar_glds16(v0, Vb, dst + AR_TILE);
-        ar_glds16(v1, Kb, dst + 1024);
-        ar_glds16(v1, Vb, dst + AR_TILE + 1024);
-    };
-    issue(0);
-    if (nt > 1) issue(1);
-
-    const int myq = q0 + rb * 32 + fl;
-    const bool active = q0 + rb * 32 < len;                 // wave-uniform
-    FwdPP z;
-    load_row_frags(z.qf, Q + (size_t)min(myq, S - 1) * ld, h2, myq < S);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z.o[nb][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) z.pa[i] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
-    z.m = -INFINITY; z.l = 0.f;
-    const float sc2 = scale * 1.4426950408889634f;
-
-    // even barrier phase 2t: tile t's pieces have landed (counted wait before the barrier), tile t+2 is issued behind it into the
-    // slot whose last reader (group 1's P V of tile t-2, phase 2t-1) is done
-    auto even_sync = [&](int t) {
-        if (t < nt) { if (t + 1 < nt) ar_wait_vm<4>(); else ar_wait_vm<0>(); }
-#ifdef FS2_DEV
-        if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && t < 64) dbg[512 + w * 64 + t] = __builtin_amdgcn_s_memtime();
-#endif
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) issue(t + 2);
-    };
-    // fragment addresses (see fwd_pp_mfma): aK for the K tile of slot 0, aV for the V tile of slot 2 (= "tile -2": stepped BEFORE use); both step one
-    // slot per multiply phase
-    unsigned aK[8], aV[8];
-    {
-        const int li = lane & 15, gq = lane >> 4, hh = gq >> 1;
-#pragma unroll
-        for (int st = 0; st < 8; ++st) aK[st] = smem_u + (unsigned)swzb(fl, 2 * st + h2);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int row = 4 * hh + (li >> 2), col = nb * 32 + 16 * (gq & 1) + 4 * (li & 3);
-            aV[2 * nb] = smem_u + (unsigned)(2 * AR_SLOT + AR_TILE + swzb(row, col >> 3) + ((col & 7) << 1));
-            aV[2 * nb + 1] = smem_u + (unsigned)(2 * AR_SLOT + AR_TILE + swzb(row + 8, col >> 3) + ((col & 7) << 1));
-        }
-    }
-    auto step = [&](unsigned (&a)[8], int from_slot) {       // slot from_slot -> from_slot + 1 (mod AR_D)
-        const int d = (from_slot & (AR_D - 1)) == AR_D - 1 ? -(AR_D - 1) * AR_SLOT : AR_SLOT;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] += (unsigned)d;
-    };
-    // (the first and the last tile step are peeled so that the loop bodies are straight-line: with the three forms of the
-    // multiply phase behind branches inside ONE loop the accumulators were written out of place and copied back every tile)
-    if (!active) {
-        for (int t = 0; t <= nt; ++t) { even_sync(t); __builtin_amdgcn_s_barrier(); }
-        return;
-    }
-    AT_STAMP(1);
-    // (MI355X_MICROARCH "two waves per SIMD", item 4: issue arbitration is priority, then AGE - the second-dispatched half loses
-    // every contested slot unless it is given static priority once; measured here: its multiply phase took 2000 cycles next to
-    // the older half's softmax, the older half's 1370 next to the younger's)
-    if (g == 1) __builtin_amdgcn_s_setprio(1);
-    if (g == 0) {
-        even_sync(0);
-        step(aV, -2); fwd_pp_mfma<false, true>(z, aV, aK); step(aK, 0);
-        __builtin_amdgcn_s_barrier();
-        fwd_pp_softmax(z, 0, len, sc2, h2);
-        for (int t = 1; t < nt; ++t) {
-            even_sync(t);
-            AT_STAMP(4 * t - 2);
-            step(aV, t - 2); fwd_pp_mfma<true, true>(z, aV, aK); step(aK, t);
-            AT_STAMP(4 * t - 1);
-            __builtin_amdgcn_s_barrier();
-            AT_STAMP(4 * t);
-            fwd_pp_softmax(z, t * 64, len, sc2, h2);
-            AT_STAMP(4 * t + 1);
-        }
-        even_sync(nt);
-        step(aV, nt - 2); fwd_pp_mfma<true, false>(z, aV, aK);
-        __builtin_amdgcn_s_barrier();
-    } else {
-        even_sync(0);
-        __builtin_amdgcn_s_barrier();
-        step(aV, -2); fwd_pp_mfma<false, true>(z, aV, aK); step(aK, 0);
-        for (int t = 1; t < nt; ++t) {
-            even_sync(t);
-            AT_STAMP(4 * t - 2);
-            fwd_pp_softmax(z, (t - 1) * 64, len, sc2, h2);
-            AT_STAMP(4 * t - 1);
-            __builtin_amdgcn_s_barrier();
-            AT_STAMP(4 * t);
-            step(aV, t - 2); fwd_pp_mfma<true, true>(z, aV, aK); step(aK, t);
-            AT_STAMP(4 * t + 1);
-        }
-        even_sync(nt);
-        fwd_pp_softmax(z, (nt - 1) * 64, len, sc2, h2);
-        __builtin_amdgcn_s_barrier();
-        step(aV, nt - 2); fwd_pp_mfma<true, false>(z, aV, aK);
-    }
-    AT_STAMP(62);
-    const float linv = z.l > 0.f ? 1.f / z.l : 0.f;
-    if (h2 == 0 && myq < S) lse_o[myq] = (z.l > 0.f) ? z.m * 0.6931471805599453f + __logf(z.l) : 0.f;
-    // lane (fl, h2) holds, for its query, the columns nb*32 + 8*(r>>2) + 4*h2 + (r&3): one v_permlane32_swap per register pair
-    // gives it two 8-column runs per 32-column block (the epilogue of fs2_gemm_epi.h)
-    bf16_t* orow = out + (size_t)myq * ldo;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        float c[2][8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            fs2_u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(z.o[nb][e]), __float_as_uint(z.o[nb][4 + e]), false, false);
-            fs2_u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(z.o[nb][8 + e]), __float_as_uint(z.o[nb][12 + e]), false, false);
-            c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
-            c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
-        }
-        if (myq < S) {
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-                uint4 ov;
-                uint32_t* ou = reinterpret_cast<uint32_t*>(&ov);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(c[ch][2 * e] * linv, c[ch][2 * e + 1] * linv);
-                *reinterpret_cast<uint4*>(orow + nb * 32 + ch * 16 + h2 * 8) = ov;
-            }
-        }
-    }
-    AT_STAMP(63);
-}
-
 extern "C" int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_t* lens, int B, int S, int H, int dk,
                             float scale, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(qkv && ctx && lse, "attn_fwd: null pointer");
@@ -927,20 +644,7 @@ extern "C" int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_
     dim3 grid(fs2_cdiv(S, 128), H, B);
     long ld = 3L * H * DK, ldo = (long)H * DK;
     if (dtype == FS2_F32) attn_fwd_kernel<float><<<grid, 256, 0, stream>>>((const float*)qkv, ld, (float*)ctx, ldo, lse, lens, S, H, scale);
-    else if (dtype == FS2_BF16) {
-        static const int abl = fs2_dev_env("FS2_ATTN_ABL", 0);
-        static const int pp = fs2_dev_env("FS2_ATTN_PP", 1);
-        if (pp && S >= 256) {
-            const int dyn = AR_D * AR_SLOT;
-            unsigned long long* dbgp = nullptr;
-#ifdef FS2_DEV
-            { const char* e = getenv("FS2_ATTN_DBG_PTR"); if (e) dbgp = (unsigned long long*)strtoull(e, nullptr, 0); }
-#endif
-            static Fs2DevOnce once;
-            once.run([&] { (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
-            attn_fwd_pp_kernel<<<dim3(fs2_cdiv(S, 256), H, B), 512, dyn, stream>>>((const bf16_t*)qkv, ld, (bf16_t*)ctx, ldo, lse, lens, S, H, scale, dbgp);
-        } else attn_fwd_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (bf16_t*)ctx, ldo, lse, lens, S, H, scale, abl);
-    }
+    else if (dtype == FS2_BF16) attn_fwd_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (bf16_t*)ctx, ldo, lse, lens, S, H, scale);
     else { fs2_set_error("attn_fwd: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("attn_fwd");
     return FS2_OK;

@@ -28,19 +28,3 @@ t = timeit(lambda: ops.attn_fwd(qkv, lens, B, S, H))
 print(f"  fwd      {t * 1e3:7.1f} us  {4 * 128 * pairs / t / 1e9:7.1f} TF (valid pairs)", flush=True)
 t = timeit(lambda: ops.attn_bwd(qkv, ctx, dctx, lse, lens, B, S, H))
 print(f"  bwd      {t * 1e3:7.1f} us  {14 * 128 * pairs / t / 1e9:7.1f} TF (7 products, valid pairs)", flush=True)
-if os.environ.get("ATTN_STAMPS"):
-    dbg = torch.zeros(16 * 64, dtype=torch.int64, device=dev)
-    os.environ["FS2_ATTN_DBG_PTR"] = str(dbg.data_ptr())
-    ops.attn_fwd(qkv, lens, B, S, H); torch.cuda.synchronize()
-    dall = dbg.cpu().view(16, 64); d = dall[:8]; dv = dall[8:]
-    t0 = int(d[:, 0].min())
-    for w in (0, 4):
-        r = [int(x) - t0 if int(x) else -1 for x in d[w]]
-        print(f"wave {w}: start {r[0]} init {r[1]} | " + " ".join(f"[t{t}: sync {r[4*t-2]} a {r[4*t-1]} bar {r[4*t]} b {r[4*t+1]}]" for t in range(1, 6)) + f" | loop end {r[62]} exit {r[63]}")
-        per = [(r[4 * t - 1] - r[4 * t - 2], r[4 * t] - r[4 * t - 1], r[4 * t + 1] - r[4 * t], (r[4 * t + 2] - r[4 * t + 1]) if t < 13 else 0) for t in range(2, 12)]
-        print("   per tile (phase A work, wait at barrier, phase B work, wait at even sync):", per)
-    for t in (5, 6):
-        print(f"tile {t}: per wave [vm-wait done, sync exit, A end, barrier exit, B end] relative to wave 0's sync exit")
-        ref = int(d[0, 4 * t - 2])
-        for w in range(8):
-            print("   wave", w, [int(dv[w, t]) - ref] + [int(d[w, 4 * t - 2 + i]) - ref for i in range(4)])
