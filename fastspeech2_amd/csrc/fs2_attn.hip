@@ -438,10 +438,16 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             if (q0 + qb * 32 >= len) break;
-            // ---- S^T = Q K^T and dP^T = dO V^T for 32 queries x my 32 keys: 16 fragment reads, then 16 MFMAs
-            bf16x8 fq[8], fd[8];
+            // ---- S^T = Q K^T and dP^T = dO V^T for 32 queries x my 32 keys, then dV += P^T dO and dK += dS^T Q.  The 32 LDS
+            // fragments of a query block travel in four batches of eight through TWO register sets, each batch requested one
+            // 8-MFMA run (256 cycles) ahead of its use.  r03m: with all 32 fragments requested up front (fq/fd/tO/tQ = 128
+            // registers next to the 64 of K/V, the 32 prefetch registers and the softmax values) the kernel needed ~350 vector
+            // registers; the compiler parked 96 of them in AGPRs and moved them with 337 v_accvgpr_read/write per 64 MFMAs -
+            // 40 % of the loop's instructions at ~5 issue cycles each.
+            const int rq = qb * 32 + fl;
+            bf16x8 fa[4], fb[4], ga[4], gb[4];
 #pragma unroll
-            for (int st = 0; st < 8; ++st) { fq[st] = frag_k(sQ, qb * 32 + fl, st, h2); fd[st] = frag_k(sdO, qb * 32 + fl, st, h2); }
+            for (int i = 0; i < 4; ++i) { fa[i] = frag_k(sQ, rq, i, h2); fb[i] = frag_k(sdO, rq, i, h2); }
             // this lane's 16 queries: rows crow(r, h2) = (r&3) + 8*(r>>2) + 4*h2 -> four float4 per array
             float4 l4[4], d4[4];
 #pragma unroll
@@ -449,24 +455,29 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
                 l4[g] = *reinterpret_cast<const float4*>(&sLD[buf][0][qb * 32 + 8 * g + 4 * h2]);
                 d4[g] = *reinterpret_cast<const float4*>(&sLD[buf][1][qb * 32 + 8 * g + 4 * h2]);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ga[i] = frag_k(sQ, rq, 4 + i, h2); gb[i] = frag_k(sdO, rq, 4 + i, h2); }
             __builtin_amdgcn_sched_barrier(0);
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[st], kf[st], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[st], vf[st], dp, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], kf[i], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], vf[i], dp, 0, 0, 0);
             }
-            // ---- transposed Q / dO fragments of the second product pair, issued before the exponentials
-            bf16x8 tO[2][4], tQ[2][4];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int nb = 0; nb < 4; ++nb) { fa[nb] = frag_t(sdO, qb * 32, nb, lane); fb[nb] = frag_t(sQ, qb * 32, nb, lane); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    tO[u][nb] = frag_t(sdO, qb * 32 + 16 * u, nb, lane);
-                    tQ[u][nb] = frag_t(sQ, qb * 32 + 16 * u, nb, lane);
-                }
+            for (int i = 0; i < 4; ++i) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[i], kf[4 + i], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb[i], vf[4 + i], dp, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) { ga[nb] = frag_t(sdO, qb * 32 + 16, nb, lane); gb[nb] = frag_t(sQ, qb * 32 + 16, nb, lane); }
             __builtin_amdgcn_sched_barrier(0);
             float pv[16], dsv[16];
 #pragma unroll
@@ -477,13 +488,20 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
                 pv[r] = p;
                 dsv[r] = p * (dp[r] - dq_);                                  // (the softmax scale multiplies dK once, at the store)
             }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                bf16x8 pa = pack8(pv + 8 * u), da = pack8(dsv + 8 * u);
+            {
+                const bf16x8 pa = pack8(pv), da = pack8(dsv);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tO[u][nb], dv[nb], 0, 0, 0);
-                    dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, tQ[u][nb], dk[nb], 0, 0, 0);
+                    dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, fa[nb], dv[nb], 0, 0, 0);
+                    dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, fb[nb], dk[nb], 0, 0, 0);
+                }
+            }
+            {
+                const bf16x8 pa = pack8(pv + 8), da = pack8(dsv + 8);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ga[nb], dv[nb], 0, 0, 0);
+                    dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, gb[nb], dk[nb], 0, 0, 0);
                 }
             }
         }
@@ -492,6 +510,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
             TILE_STORE_REGS(sQD[buf ^ 1][1], td);
             if (tid < 128) sLD[buf ^ 1][tid >> 6][tid & 63] = tl;
         }
+        // the eight accumulators are pinned to the accumulation registers across the loop edge: left to itself the allocator carried
+        // them in VGPRs from one tile to the next and moved all 128 values into AGPRs and back around every tile's MFMAs
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) asm volatile("" : "+a"(dk[nb]), "+a"(dv[nb]));
         __syncthreads();
     }
 #pragma unroll

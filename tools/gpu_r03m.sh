@@ -1,4 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python tools/ab_env.py "" FS2_ATTN_PP=0 > gpurun_out/r03m_ab_env.log 2>&1; cat gpurun_out/r03m_ab_env.log
+( timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_a_prodshape_gpu.py -q -x -k "attention" ) > gpurun_out/r03m_pytest_attn.log 2>&1; tail -5 gpurun_out/r03m_pytest_attn.log | cut -c1-300
+timeout 300 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03m_attn.log 2>&1; cat gpurun_out/r03m_attn.log
