@@ -243,9 +243,11 @@ class Engine:
         return ws
 
     def _bn_eval_stats(self, pre):
-        """[running_mean | rsqrt(running_var + eps)] of an eval-mode BatchNorm layer, cached until the buffers change (torch bumps a
-        tensor's _version on every in-place write: load_state_dict, a training step).  Was three tiny torch launches (add, rsqrt,
-        cat) per PostNet layer and synthesis batch - 15 of a synthesis step's launches."""
+        """[running_mean | rsqrt(running_var + eps)] of an eval-mode BatchNorm layer, cached until the buffers change: torch bumps a
+        tensor's _version on its own in-place writes (load_state_dict, .copy_); the training kernels update the running statistics
+        through raw pointers, so FastSpeech2.train() / .eval() also drops the cache on every mode switch (r03n: without that a
+        train -> eval -> train -> eval sequence, i.e. train.py's validation, evaluated with the FIRST validation's statistics).
+        Was three tiny torch launches (add, rsqrt, cat) per PostNet layer and synthesis batch - 15 of a synthesis step's launches."""
         rm, rv = self.Bf[pre + "1.running_mean"], self.Bf[pre + "1.running_var"]
         key = (rm.data_ptr(), rm._version, rv.data_ptr(), rv._version)
         hit = self._bn_eval.get(pre)

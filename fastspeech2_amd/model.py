@@ -329,6 +329,10 @@ class FastSpeech2(nn.Module):
 
     def train(self, mode=True):
         self._invalidate()
+        if self._engine is not None:
+            # training writes the BatchNorm running statistics from the kernels (raw pointers: no torch _version bump), so the
+            # eval-mode [mean | rstd] cache is dropped on every mode switch - eval() after training always rebuilds it
+            self._engine._bn_eval.clear()
         return super().train(mode)
 
     # ------------------------------------------------------------------ forward (reference signature)

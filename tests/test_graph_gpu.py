@@ -49,13 +49,14 @@ def test_graph_replay_matches_eager_steps(dev, side_stream):
     lg, mg, pg, bng = _run(dev, True, side_stream)
     assert torch.allclose(le, lg, rtol=2e-5, atol=1e-5), (le, lg)       # fresh dropout masks on every replay, same sequence as eager
     # Adam's first moments = every gradient of every step.  Two EAGER runs of the same seeded steps already differ (fp32 weight
-    # gradients are summed with atomics; observed 2e-4 .. 1e-3 after 7 steps): the graph run must sit within a few times that
-    # run-to-run distance - the two bugs this test was written for (identical masks on every replay, BatchNorm sums accumulating
-    # across replays) move it by O(0.1 - 1).
+    # gradients are summed with atomics; observed 2e-4 .. 1e-3 after 7 steps, but on some boxes two eager runs schedule
+    # identically and agree to 7e-7 while the captured single-stream run still sits 7e-4 away): the graph run must sit within a
+    # few times the largest run-to-run distance seen - the two bugs this test was written for (identical masks on every replay,
+    # BatchNorm sums accumulating across replays) move it by O(0.1 - 1).
     noise = float((me2 - me).norm() / me.norm())
     rel = float((mg - me).norm() / me.norm())
     print(f"side_stream={side_stream}: eager-vs-eager {noise:.2e}, graph-vs-eager {rel:.2e}")
-    assert rel < 4 * noise + 3e-4, (rel, noise)
+    assert rel < 4 * noise + 4e-3, (rel, noise)
     for k in bne:
         assert torch.allclose(bne[k].float(), bng[k].float(), rtol=1e-5, atol=1e-6), k
     assert float((pg - pe).abs().max()) < 1e-5                          # 7 warm-up-rate Adam steps: |dp| <= ~2e-6 each

@@ -514,5 +514,11 @@ def test_conv_gemm_big_tile_lrelu_prologue(dev, B, S, C, N, k, dil):
     got = ops.conv_gemm(x, w, b, S, taps=k, dil=dil, pad=pad, in_act=ops.ACT_LRELU, in_slope=0.1)
     xl = torch.nn.functional.leaky_relu(x.float(), 0.1).to(torch.bfloat16)
     ref = ops.conv_gemm(xl, w, b, S, taps=k, dil=dil, pad=pad)
-    # both calls take the ring kernel (>= 170 tiles): same accumulation order, same bf16 rounding of the activation
-    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    # same kernel for both calls (the multi-tap shapes): same accumulation order, same bf16 rounding of the activation -> equal
+    # bits.  The one-tap shape takes the persistent kernel WITH the prologue and the wide one-tap kernel (K-steps of 32) without
+    # it: same products, different fp32 summation order -> at most one bf16 ulp apart.
+    if k > 1:
+        assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    else:
+        d = (got.float() - ref.float()).abs()
+        assert bool((d <= 2.0 ** -7 * ref.float().abs() + 1e-3).all()), d.max().item()
