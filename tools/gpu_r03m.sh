@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( time timeout 1500 python -m pytest tests/test_graph_gpu.py tests/test_cli_gpu.py tests/test_ops_gpu.py -m gpu -q -k "graph or cli or lrelu_prologue" ) > gpurun_out/r03n_pytest_fix.log 2>&1; tail -5 gpurun_out/r03n_pytest_fix.log | cut -c1-300
+FS2_LIB_PATH=$PWD/fastspeech2_amd/libfs2hip_dev.so W_STAMPS=1 timeout 300 python tools/bench_w.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03o_bench_w.log; cat gpurun_out/r03o_bench_w.log
