@@ -1,4 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for g in 0 64 128 256; do echo "FS2_W_STAGGER=$g"; FS2_LIB_PATH=$PWD/fastspeech2_amd/libfs2hip_dev.so FS2_W_STAGGER=$g timeout 300 python tools/bench_w.py 2>&1 | grep -v amdgpu.ids | grep -E "qkv fwd|w_2 dgrad|per dec"; done > gpurun_out/r03q_bench_w_stagger.log; cat gpurun_out/r03q_bench_w_stagger.log
+( time timeout 1500 python -m pytest tests -m gpu -q ) > gpurun_out/r03r_pytest_full.log 2>&1; tail -6 gpurun_out/r03r_pytest_full.log | cut -c1-300
+timeout 600 python bench.py > gpurun_out/r03r_bench_bf16.log 2>&1; tail -1 gpurun_out/r03r_bench_bf16.log | cut -c1-400
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
