@@ -626,11 +626,18 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 }
             }
             float dsv[16];
-            const bool tail = k0 + kb * 32 + 32 > len;                     // block-uniform: the only key block with padded keys
+            // the only key block with padded keys gets its scores masked BEFORE the exponential, behind a wave-uniform branch (as a
+            // per-element select in the common loop it was 94 of the loop's 310 VALU instructions: r03m instruction mix)
+            if (k0 + kb * 32 + 32 > len) {
+                int thr = len - k0 - kb * 32 - 4 * h2;
+                asm volatile("" : "+v"(thr));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) >= thr) s[r] = -INFINITY;           // exp2(-inf) = 0
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -my_lse2));
-                if (tail && k0 + kb * 32 + crow(r, h2) >= len) p = 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -my_lse2));
                 dsv[r] = p * (dp[r] - my_del);                                  // (the softmax scale multiplies dQ once, at the store)
             }
 #pragma unroll
