@@ -67,6 +67,14 @@ class Engine:
         self._side_keep = []
         self._ln_pending = []
         self.defer_ln_reduce = True
+        # The FFT blocks' contractions do NOT carry lens (r03u): with it the persistent / wide kernels leave out the 2 % of 256-row
+        # tiles that lie wholly in a sequence's tail and zero the padded rows of real tiles in their epilogue - and run slower for
+        # it (k = 9 forward convolution 209-217 us with lens, 189 us without, `profiles/r03u_bench_conv.log`; step -0.07 ms,
+        # `r03u_ab_env.log`).  Nothing needs those zeros: LayerNorm (forward and backward) masks padded rows itself, attention
+        # and the weight gradients never read rows t >= lens[b], and every backward operand is exactly zero there already
+        # (ln_bwd / attn_bwd write zeros), so the padded rows of the results are finite values nobody consumes.
+        self.gemm_lens_fwd = False
+        self.gemm_lens_bwd = False
         self.fuse_proj_ln = False       # see _proj_ln: the one-launch form is measured slower at the bench shape
         self._pack_pending = False
         self._bn_ws = {}
@@ -265,8 +273,11 @@ class Engine:
 
     def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
         wf, _, b, shape = W[key]
+        ragged = lens is not None
+        if not self.gemm_lens_fwd:
+            lens = None
         return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res, tmap=self._tmap(lens),
-                             tail_ws=self._tail_workspace(x.device))
+                             tail_ws=self._tail_workspace(x.device), ragged=ragged)
 
     def _proj_ln(self, W, key, x, res, ln, lens, B, S, p, site, seed_dev):
         """N = 256 projection -> dropout -> + residual -> LayerNorm.  Returns (z, out, mean, rstd) with z = what ln_bwd needs.
@@ -288,10 +299,13 @@ class Engine:
     def _dgemm(self, W, key, dy, S, taps=1, pad=0, act=ACT_NONE, res=None, lens=None):
         """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
         _, wd, _, shape = W[key]
+        ragged = lens is not None
+        if not self.gemm_lens_bwd:
+            lens = None
         # (few-tile, long-reduction shapes - the encoder's k=9 data gradient, 48 tiles x 144 K-steps - are split by the same
         # tail mechanism: a launch with fewer tiles than CUs is all tail)
         return ops.conv_gemm(dy, wd, None, S, taps=taps, pad=(taps - 1) - pad, act=act, res=res, lens=lens, tmap=self._tmap(lens),
-                             tail_ws=self._tail_workspace(dy.device))
+                             tail_ws=self._tail_workspace(dy.device), ragged=ragged)
 
     def _tail_workspace(self, device):
         """scratch of the persistent kernel's tail split: one per stream the engine launches contractions on (launches that

@@ -91,9 +91,11 @@ def pack_weight(w, dtype, want_fwd=True, want_dgrad=True, wf=None, wd=None):
 # ------------------------------------------------------------------ contraction
 def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0, lens=None, res=None, out=None,
               in_act=ACT_NONE, in_slope=0.0, accumulate=False, out_scale=1.0, ldx=None, M=None, Cin=None, N=None,
-              ldy=None, tmap=None, ksplit=1, ws=None, tail_ws=None):
+              ldy=None, tmap=None, ksplit=1, ws=None, tail_ws=None, ragged=None):
     """x: [M, Cin] rows (or any buffer with row stride ldx); wpacked: [N, taps, Cin]; returns [M, N].
     tmap: tile_map(lens, B, S) of the same lens (optional; lets the persistent kernel skip fully padded M-tiles).
+    ragged: bookkeeping only (bench.py's valid-row FLOP count) - the rows hold ragged sequences although the launch itself does
+    not carry lens (it computes the padded rows too: see Engine.gemm_lens_*).
     tail_ws: tail_workspace(device) scratch (optional; lets the persistent kernel K-split its last partial round of tiles)."""
     if M is None:
         M = x.shape[0]
@@ -126,7 +128,7 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
         var = 5 if ksplit > 1 and taps > 1 else (6 if ksplit > 1 else
               _lib.load().fs2_conv_gemm_variant(ldx, ldy, ldr, int(lens is not None), int(tmap is not None), M, N, Cin, S, taps, dil,
                                                 in_act, in_slope, dt(x)))
-        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, var, lens is not None, S))
+        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, var, (lens is not None) or bool(ragged), S))
     return out
 
 

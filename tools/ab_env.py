@@ -26,6 +26,10 @@ def one():
         model._engine.fuse_proj_ln = True
     if os.environ.get("AB_WGRAD_LATE") == "0":
         model._engine.wgrad_after_dgrad = False
+    if os.environ.get("AB_LENS_FWD") == "0":
+        model._engine.gemm_lens_fwd = False
+    if os.environ.get("AB_LENS_BWD") == "0":
+        model._engine.gemm_lens_bwd = False
     if os.environ.get("AB_SIDE") == "0":
         model._engine.use_side_stream = False
     # (stream priorities: torch.cuda.Stream.priority_range() is (0, -1) on this stack - the step runs on -1, the side stream on 0;

@@ -16,7 +16,8 @@ valid = int(lens.sum().item())
 tmap = ops.tile_map(lens, B, S)
 tws = ops.tail_workspace(dev)
 # (name, Cin, N, taps, residual, act, lens?)
-SHAPES = [("ffn k9 fwd+relu", 256, 1024, 9, False, ops.ACT_RELU, True), ("ffn k9 dgrad+res", 1024, 256, 9, True, ops.ACT_NONE, True),
+SHAPES = [("ffn k9 fwd+relu", 256, 1024, 9, False, ops.ACT_RELU, True), ("ffn k9 fwd+relu (no lens)", 256, 1024, 9, False, ops.ACT_RELU, False),
+          ("ffn k9 dgrad+res", 1024, 256, 9, True, ops.ACT_NONE, True), ("ffn k9 dgrad+res (no lens)", 1024, 256, 9, True, ops.ACT_NONE, False),
           ("postnet k5 fwd", 512, 512, 5, False, ops.ACT_NONE, False), ("postnet k5 dgrad", 512, 512, 5, False, ops.ACT_NONE, False),
           ("postnet k5 80->512", 80, 512, 5, False, ops.ACT_NONE, False), ("postnet k5 512->80", 512, 80, 5, False, ops.ACT_NONE, False),
           ("pred k3 256->256", 256, 256, 3, False, ops.ACT_RELU, False)]
@@ -41,4 +42,4 @@ for name, K, N, taps, res, act, use_lens in SHAPES:
         ts.append(e0.elapsed_time(e1) / 10)
     ms = sorted(ts)[2]
     rows = valid if use_lens else M
-    print(f"  {name:20s} Cin={K:4d} N={N:4d} taps {taps}: {ms * 1e3:7.1f} us  {2.0 * rows * K * taps * N / ms / 1e9:7.1f} TF (valid rows {rows})", flush=True)
+    print(f"  {name:28s} Cin={K:4d} N={N:4d} taps {taps}: {ms * 1e3:7.1f} us  {2.0 * rows * K * taps * N / ms / 1e9:7.1f} TF (valid rows {rows})", flush=True)
