@@ -137,7 +137,8 @@ def build(args, device, rank, world, dtype=None):
             b["mels"] = (torch.clamp(torch.randn(args.batch, T, 80, generator=g) * 2 - 5, -11.5, 2.0) * mv).float()
             b["pitches"] = (torch.clamp(torch.randn(args.batch, L, generator=g), -2.917, 11.391) * sv).float()
             b["energies"] = (torch.clamp(torch.randn(args.batch, L, generator=g), -1.431, 8.184) * sv).float()
-    b = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    from fastspeech2_amd.utils import lens_to_device
+    b = {k: (lens_to_device(v, device) if k in ("src_lens", "mel_lens") else v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     loss_fn = FastSpeech2Loss(pcfg, mcfg, count_reduce=ddp.CountExchange() if world > 1 else None)
     opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
     opt._ensure()

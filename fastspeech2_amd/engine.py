@@ -67,14 +67,19 @@ class Engine:
         self._side_keep = []
         self._ln_pending = []
         self.defer_ln_reduce = True
-        # The FFT blocks' contractions do NOT carry lens (r03u): with it the persistent / wide kernels leave out the 2 % of 256-row
-        # tiles that lie wholly in a sequence's tail and zero the padded rows of real tiles in their epilogue - and run slower for
-        # it (k = 9 forward convolution 209-217 us with lens, 189 us without, `profiles/r03u_bench_conv.log`; step -0.07 ms,
-        # `r03u_ab_env.log`).  Nothing needs those zeros: LayerNorm (forward and backward) masks padded rows itself, attention
-        # and the weight gradients never read rows t >= lens[b], and every backward operand is exactly zero there already
-        # (ln_bwd / attn_bwd write zeros), so the padded rows of the results are finite values nobody consumes.
-        self.gemm_lens_fwd = False
-        self.gemm_lens_bwd = False
+        # Whether the FFT blocks' contractions carry lens is decided PER BATCH (r03u / r03z).  With lens the persistent / wide
+        # kernels leave out the 256-row tiles that lie wholly in a sequence's tail and zero the padded rows of the others in
+        # their epilogue - and that epilogue and the tile-map walk cost more than they save when few tiles can be left out: the
+        # LJSpeech bench batch (2 % of the tiles) runs the k = 9 forward convolution in 209-217 us with lens and 189 us
+        # without (`profiles/r03u_bench_conv.log`; step -0.07 ms), the LibriTTS-shaped bucket (46 % valid rows, ~40 % of the
+        # tiles) runs the step in 8.94 ms with lens and 9.26 without (`profiles/r03z_ab_env_libritts.log`).  Nothing needs the
+        # zeros: LayerNorm (forward and backward) masks padded rows itself, attention and the weight gradients never read rows
+        # t >= lens[b], and every backward operand is exactly zero there already, so without lens the padded rows of the results
+        # are finite values nobody consumes.  The decision uses the lengths' HOST copy (utils.lens_to_device: no device round
+        # trip); a lengths vector without one (inference: frame counts are computed on the device) runs without lens.
+        self.gemm_lens_fwd = None       # None: per batch (skippable-tile fraction >= lens_skip_min); True / False: forced
+        self.gemm_lens_bwd = None
+        self.lens_skip_min = 0.10
         self.fuse_proj_ln = False       # see _proj_ln: the one-launch form is measured slower at the bench shape
         self._pack_pending = False
         self._bn_ws = {}
@@ -264,6 +269,30 @@ class Engine:
             self._bn_eval[pre] = hit
         return hit[1]
 
+    def _lens_pays(self, lens, forced):
+        if lens is None:
+            return False
+        if forced is not None:
+            return bool(forced)
+        return getattr(lens, "_fs2_skip", 0.0) >= self.lens_skip_min
+
+    @staticmethod
+    def _skip_fraction(host_lens, S):
+        """fraction of the 256-row M-tiles of the [B * S] row space that lie wholly inside one sequence's padded tail (what
+        fs2_tile_map lists as padded), from the lengths' host copy; 0 when there is none."""
+        if host_lens is None:
+            return 0.0
+        import numpy as np
+        lens = np.minimum(np.asarray(host_lens, dtype=np.int64), S)
+        M = int(len(lens)) * int(S)
+        if M == 0:
+            return 0.0
+        m0 = np.arange(0, M, ops.TILE_ROWS, dtype=np.int64)
+        mlast = np.minimum(m0 + ops.TILE_ROWS - 1, M - 1)
+        b0, b1 = m0 // S, mlast // S
+        padded = (b0 == b1) & ((m0 - b0 * S) >= lens[b0])
+        return float(padded.mean())
+
     @staticmethod
     def _tmap(lens):
         """tile map that ops.lens_prep made together with this lengths tensor (None otherwise: the non-persistent kernels run).
@@ -274,7 +303,7 @@ class Engine:
     def _gemm(self, W, key, x, S, taps=1, pad=0, act=ACT_NONE, lens=None, res=None):
         wf, _, b, shape = W[key]
         ragged = lens is not None
-        if not self.gemm_lens_fwd:
+        if not self._lens_pays(lens, self.gemm_lens_fwd):
             lens = None
         return ops.conv_gemm(x, wf, b, S, taps=taps, pad=pad, act=act, lens=lens, res=res, tmap=self._tmap(lens),
                              tail_ws=self._tail_workspace(x.device), ragged=ragged)
@@ -300,7 +329,7 @@ class Engine:
         """data gradient through the contraction `key` (tap-flipped pack; pad' = (k-1) - pad)."""
         _, wd, _, shape = W[key]
         ragged = lens is not None
-        if not self.gemm_lens_bwd:
+        if not self._lens_pays(lens, self.gemm_lens_bwd):
             lens = None
         # (few-tile, long-reduction shapes - the encoder's k=9 data gradient, 48 tiles x 144 K-steps - are split by the same
         # tail mechanism: a launch with fewer tiles than CUs is all tail)
@@ -547,6 +576,7 @@ class Engine:
         p_pn = 0.5 if drop else 0.0
         st.counts = torch.empty(2, device=self.device, dtype=torch.float32)
         src_lens32, st.src_masks, src_lens32._fs2_tmap = ops.lens_prep(st.src_lens, B, L, st.counts[0:1])
+        src_lens32._fs2_skip = self._skip_fraction(getattr(st.src_lens, "_fs2_host", None), L)
 
         # ---- encoder (transformer/Models.py:73-100)
         n_head = self.tc["encoder_head"]
@@ -611,6 +641,8 @@ class Engine:
         cum, idx, mel_len = ops.lr_index(dur, Tdec)
         st.mel_lens_out, st.Tdec = mel_len, Tdec
         dec_lens32, st.mel_masks, dec_lens32._fs2_tmap = ops.lens_prep(mel_len, B, Tdec, st.counts[1:2])
+        # (training: the frame counts equal the batch's mel_lens - sum of the target durations - whose host copy came with the batch)
+        dec_lens32._fs2_skip = self._skip_fraction(getattr(st.mel_lens, "_fs2_host", None) if st.d_t is not None else None, Tdec)
         frame_level = (not pitch_phone) or (not energy_phone)
         pe_dec = self._pe(P["decoder.position_enc"], Tdec)
         sv.x_lr_in = None

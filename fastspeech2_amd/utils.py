@@ -110,15 +110,25 @@ def to_device(data, device):
         ids, raw_texts, speakers, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, pitches, energies, durations = data
         return (ids, raw_texts,
                 torch.from_numpy(speakers).long().to(device), torch.from_numpy(texts).long().to(device),
-                torch.from_numpy(src_lens).to(device), max_src_len,
-                torch.from_numpy(mels).float().to(device), torch.from_numpy(mel_lens).to(device), max_mel_len,
+                lens_to_device(src_lens, device), max_src_len,
+                torch.from_numpy(mels).float().to(device), lens_to_device(mel_lens, device), max_mel_len,
                 torch.from_numpy(pitches).float().to(device), torch.from_numpy(energies).to(device),
                 torch.from_numpy(durations).long().to(device))
     if len(data) == 6:
         ids, raw_texts, speakers, texts, src_lens, max_src_len = data
         return (ids, raw_texts, torch.from_numpy(speakers).long().to(device), torch.from_numpy(texts).long().to(device),
-                torch.from_numpy(src_lens).to(device), max_src_len)
+                lens_to_device(src_lens, device), max_src_len)
     raise ValueError(f"to_device: batch of length {len(data)} (expected 12 or 6)")
+
+
+def lens_to_device(lens, device):
+    """a lengths vector (numpy or CPU tensor) -> device tensor that also carries its HOST copy (`_fs2_host`, numpy): the engine
+    decides from it, without a device round trip, whether a batch is padded enough for the contractions to skip tiles
+    (Engine.lens_skip_min)."""
+    host = lens.numpy() if torch.is_tensor(lens) else np.asarray(lens)
+    t = torch.from_numpy(np.ascontiguousarray(host)).to(device)
+    t._fs2_host = host
+    return t
 
 
 def get_mask_from_lengths(lengths, max_len=None):

@@ -155,3 +155,32 @@ def test_mel_filterbank_equals_the_independent_decimal_computation():
             i, k = map(int, key.split(","))
             assert struct.unpack("<I", struct.pack("<f", float(t[i, k])))[0] == bits, (name, key)
         assert [int(np.nonzero(r)[0][0]) for r in t] == g["first_nonzero"] and [int(np.nonzero(r)[0][-1]) for r in t] == g["last_nonzero"]
+
+
+def test_padded_tile_fraction_from_the_host_copy_of_the_lengths():
+    """Engine._skip_fraction (the per-batch decision whether the FFT blocks' contractions carry lens) == the rule fs2_tile_map
+    applies on the device: a 256-row tile of the [B * S] row space is padded when all of its rows lie in ONE sequence's tail;
+    utils.lens_to_device hands the engine the host copy it needs."""
+    import numpy as np
+    import torch
+    from fastspeech2_amd.engine import Engine
+    from fastspeech2_amd.utils import lens_to_device
+
+    def brute(lens, S, rows=256):
+        M = len(lens) * S
+        n = pad = 0
+        for m0 in range(0, M, rows):
+            ms = range(m0, min(m0 + rows, M))
+            n += 1
+            pad += all((m % S) >= min(lens[m // S], S) for m in ms) and len({m // S for m in ms}) == 1
+        return pad / n
+
+    rng = np.random.RandomState(5)
+    for B, S in ((48, 925), (48, 988), (3, 100), (7, 256), (5, 1000)):
+        for lo in (0.05, 0.5, 0.9):
+            lens = rng.randint(int(S * lo), S + 1, size=B)
+            assert abs(Engine._skip_fraction(lens, S) - brute(lens.tolist(), S)) < 1e-12, (B, S, lo)
+    assert Engine._skip_fraction(None, 925) == 0.0
+    assert Engine._skip_fraction(np.full(48, 925), 925) == 0.0
+    t = lens_to_device(np.array([5, 3, 9], dtype=np.int64), torch.device("cpu"))
+    assert t.dtype == torch.int64 and t.tolist() == [5, 3, 9] and t._fs2_host.tolist() == [5, 3, 9]

@@ -11,7 +11,7 @@ def one():
     import torch
     import bench
     class A: pass
-    a = A(); a.dtype = "bf16"; a.batch = 48; a.phonemes = 128; a.workload = "ljspeech"; a.dec_layers = 4; a.frame_level = False; a.side_stream = 1
+    a = A(); a.dtype = "bf16"; a.batch = 48; a.phonemes = 128; a.workload = os.environ.get("AB_WORKLOAD", "ljspeech"); a.dec_layers = 4; a.frame_level = False; a.side_stream = 1
     dev = torch.device("cuda:0")
     torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     model, loss_fn, opt, b, _, _ = bench.build(a, dev, 0, 1)
@@ -26,10 +26,10 @@ def one():
         model._engine.fuse_proj_ln = True
     if os.environ.get("AB_WGRAD_LATE") == "0":
         model._engine.wgrad_after_dgrad = False
-    if os.environ.get("AB_LENS_FWD") == "0":
-        model._engine.gemm_lens_fwd = False
-    if os.environ.get("AB_LENS_BWD") == "0":
-        model._engine.gemm_lens_bwd = False
+    if os.environ.get("AB_LENS_FWD") in ("0", "1"):          # FFT-block contractions with / without lens (default: without)
+        model._engine.gemm_lens_fwd = os.environ["AB_LENS_FWD"] == "1"
+    if os.environ.get("AB_LENS_BWD") in ("0", "1"):
+        model._engine.gemm_lens_bwd = os.environ["AB_LENS_BWD"] == "1"
     if os.environ.get("AB_SIDE") == "0":
         model._engine.use_side_stream = False
     # (stream priorities: torch.cuda.Stream.priority_range() is (0, -1) on this stack - the step runs on -1, the side stream on 0;
