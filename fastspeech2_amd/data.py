@@ -256,6 +256,8 @@ class DevicePrefetcher:
                 else:
                     for i, dt_ in dts.items():
                         out[i] = self._stage(slot, i, np.asarray(b[i]).astype(dt_, copy=False))
+                for i in ((4, 7) if len(b) == 12 else (4,)):    # lengths vectors carry their host copy (utils.lens_to_device's contract:
+                    out[i]._fs2_host = np.asarray(b[i])            # the engine reads the padding fraction from it without a device round trip)
                 self.q.put((tuple(out), ev))
         except BaseException as e:  # surfaced on the consumer side
             self._err = e
