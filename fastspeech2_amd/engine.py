@@ -9,6 +9,7 @@ memory).  All launches go to the current HIP stream with static shapes -> the fu
 
 Activation layout: time-major rows [B*S, C]; padding handled by per-sequence lengths (int32), never by masks.
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -282,7 +283,6 @@ class Engine:
         fs2_tile_map lists as padded), from the lengths' host copy; 0 when there is none."""
         if host_lens is None:
             return 0.0
-        import numpy as np
         lens = np.minimum(np.asarray(host_lens, dtype=np.int64), S)
         M = int(len(lens)) * int(S)
         if M == 0:
