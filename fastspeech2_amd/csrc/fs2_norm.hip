@@ -560,11 +560,14 @@ struct BnArgs {
     float p; uint64_t seed; const uint64_t* seed_dev;
 };
 
-// tanh through one v_exp_f32 and one reciprocal (|error| < 2e-7 absolute; tanhf's branchy polynomial costs ~3x as much
-// and runs three times per PostNet element: forward, backward sums, backward dx)
+// tanh through one v_exp_f32 and one v_rcp_f32 (|error| < 3e-7 absolute; tanhf's branchy polynomial costs ~3x as much
+// and runs three times per PostNet element: forward, backward sums, backward dx).  The reciprocal is the hardware one (1 ulp):
+// written as 2.f / (e + 1.f) hipcc emits the IEEE division sequence (v_div_scale x 2, v_rcp, four v_fma, v_div_fmas,
+// v_div_fixup - r04 ISA: 82 v_div_scale in the backward kernels' unrolled bodies), ~10 instructions per element and pass in
+// kernels that are VALU-bound (2.3-3.3 TB/s against LayerNorm's 5+).
 __device__ __forceinline__ float fs2_tanh(float x) {
     float e = __expf(2.f * fabsf(x));
-    float t = 1.f - 2.f / (e + 1.f);              // e = +inf -> 1
+    float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);              // e = +inf -> rcp = 0 -> 1
     return copysignf(t, x);
 }
 

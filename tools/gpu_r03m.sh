@@ -1,5 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 600 python bench.py --no-cpu-baseline --no-fp32 --no-synth > gpurun_out/r04c_bench_bf16.log 2>&1; tail -1 gpurun_out/r04c_bench_bf16.log | cut -c1-330
+( timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_a_prodshape_gpu.py tests/test_model_gpu.py -q -x -k "batch_norm or batchnorm or bn_ or postnet or model or parity or step" ) > gpurun_out/r04e_pytest_bn.log 2>&1; tail -3 gpurun_out/r04e_pytest_bn.log | cut -c1-300
+timeout 300 python tools/ab_env.py "" > gpurun_out/r04e_ab.log 2>&1; cat gpurun_out/r04e_ab.log
