@@ -114,5 +114,7 @@ def test_prefetcher_host_path(tmp_path):
             assert isinstance(g[j], torch.Tensor)
             assert np.array_equal(g[j].numpy(), np.asarray(r[j]).astype(g[j].numpy().dtype))
         assert g[3].dtype == torch.int64 and g[6].dtype == torch.float32 and g[11].dtype == torch.int64
+        # the two lengths vectors carry their host copy (what Engine._lens_pays reads instead of a device round trip)
+        assert np.array_equal(g[4]._fs2_host, np.asarray(r[4])) and np.array_equal(g[7]._fs2_host, np.asarray(r[7]))
     with pytest.raises(ValueError):
         list(DevicePrefetcher(iter([(1, 2, 3)]), "cpu"))
