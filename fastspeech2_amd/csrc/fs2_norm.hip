@@ -552,9 +552,10 @@ extern "C" int fs2_ln_bwd_reduce(const float* partial_ws, int C, float* dgamma, 
 struct BnArgs {
     const void* x; const void* dout; const void* res; void* out;
     const float* mean_rstd; const float* gamma; const float* beta;
-    float* sums;                 // stats / bwd sums (2C floats, atomically accumulated)
+    float* sums;                 // stats / bwd sums (2C floats): WRITTEN by the last row group of each channel block (reducing modes)
+    float* slab;                 // reducing modes: [row group][pass][C] partial sums (plain stores; summed in index order)
+    unsigned* counter;           // reducing modes: one arrival counter per channel block; zero between launches
     float* acc_dbeta; float* acc_dgamma;   // MODE 3 (optional): parameter gradients += sums (workgroup 0)
-    float* clear;                // MODE 3 (optional): 2C floats zeroed by workgroup 0 (the NEXT call's sums)
     int M, C, cprp, rows_per_block, act;
     int cblk;                    // channels per workgroup (grid.y walks the channel blocks); cprp * V when one workgroup spans the row
     float p; uint64_t seed; const uint64_t* seed_dev;
@@ -572,9 +573,15 @@ __device__ __forceinline__ float fs2_tanh(float x) {
 }
 
 // MODE 0: statistics   1: apply   2: backward pass 1 (sums)   3: backward pass 2 (dx)
-// Reducing modes (0, 2) run FEW fat workgroups (NT = 1024 threads, 4 rows in flight per thread): every workgroup ends with
-// 2C same-address atomics that all land on the same ~32 cache lines, so their number - not the streaming - sets the time
-// (1024 workgroups: 103-118 us per pass; ~100: the HBM time).  Streaming modes (1, 3) use many 256-thread workgroups.
+// Reducing modes (0, 2) run FEW fat workgroups (NT = 1024 threads, 4 rows in flight per thread).  Streaming modes (1, 3) use
+// many 256-thread workgroups.
+// The column sums are BIT-REPRODUCIBLE (r04): a workgroup stores its partial sums into its own row of a slab, and the LAST
+// workgroup to arrive at a channel block (device-scope counter) adds the partials in row-group order.  Rounds 1-3 used one
+// float atomic per channel and workgroup: the arrival order changed the last bits of mean / rstd / the backward sums from run to
+// run, bf16 rounding turned some of those into one-spacing differences in the PostNet's tensors, and the whole-step gradient
+// moved between runs of the same binary (profiles/r04a_spread_seed0.log: 6 runs, 6 different flat-gradient hashes, the
+// mel_linear.weight error 0.77 x .. 2.47 x the emulated one; r04b_spread_local.log: the first tensors that differ are the ones
+// behind the first BatchNorm).
 // V = channels per thread: 4 (8 / 16 bytes per access) or, for bf16 with C % 8 == 0, 8 (16-byte lanes: r02 PMC showed the
 // 8-byte version streaming at 1.5-3.5 TB/s with the per-thread bytes in flight as the limiter).
 template <typename T, int V> __device__ __forceinline__ void bn_ldv(const T* p, float* f) {
@@ -613,14 +620,11 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
             }
         }
     }
-    if (MODE == 3 && blockIdx.x == 0 && rl == 0 && cok) {
+    if (MODE == 3 && blockIdx.x == 0 && rl == 0 && cok && a.acc_dbeta) {
         // the reduced sums ARE the affine gradients (sum g = dbeta, sum g*xhat = dgamma): workgroup 0 adds them into the
-        // parameter-gradient buffers and clears the workspace the next call reduces into (ping-pong: nobody reads that one now)
+        // parameter-gradient buffers
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            if (a.acc_dbeta) { a.acc_dbeta[c + k] += a.sums[c + k]; a.acc_dgamma[c + k] += a.sums[a.C + c + k]; }
-            if (a.clear) { a.clear[c + k] = 0.f; a.clear[a.C + c + k] = 0.f; }
-        }
+        for (int k = 0; k < V; ++k) { a.acc_dbeta[c + k] += a.sums[c + k]; a.acc_dgamma[c + k] += a.sums[a.C + c + k]; }
     }
     float a1[V], a2[V];
 #pragma unroll
@@ -679,7 +683,8 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
             row(r, v1, g1);
         }
     }
-    if (MODE == 0 || MODE == 2) {                      // tree over the block's row lanes in LDS, then one atomic per channel
+    if (MODE == 0 || MODE == 2) {                      // tree over the block's row lanes in LDS, then one slab row per workgroup
+        __shared__ int s_last;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (pass) __syncthreads();
@@ -695,8 +700,38 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
             }
             if (rl == 0 && cok) {
 #pragma unroll
-                for (int k = 0; k < V; ++k) atomicAdd(a.sums + (pass ? a.C : 0) + c + k, s_red[threadIdx.x * V + k]);
+                for (int k = 0; k < V; ++k) a.slab[((size_t)blockIdx.x * 2 + pass) * a.C + c + k] = s_red[threadIdx.x * V + k];
             }
+        }
+        // publish the slab row, then elect the last row group of this channel block (the threadFenceReduction pattern: the
+        // device-scope fence orders the stores above before the counter update and the loads below after it)
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(a.counter + blockIdx.y, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            // 2 * cblk sums, each over gridDim.x partials IN INDEX ORDER.  NT / nsum threads share a sum (strided by `parts`), their
+            // partial results meet in LDS and are added in `part` order: the association is a function of the launch geometry only.
+            const int nsum = 2 * a.cblk;
+            const int parts = NT >= nsum ? NT / nsum : 1;
+            for (int base = 0; base < nsum; base += NT) {
+                const int sidx = base + (int)(threadIdx.x % (unsigned)min(nsum, NT)), part = threadIdx.x / min(nsum, NT);
+                const int pass = sidx / a.cblk, cc = blockIdx.y * a.cblk + sidx % a.cblk;
+                float t = 0.f;
+                if (sidx < nsum && cc < a.C && part < parts) {
+                    for (int j = part; j < (int)gridDim.x; j += parts) t += a.slab[((size_t)j * 2 + pass) * a.C + cc];
+                }
+                __syncthreads();
+                s_red[threadIdx.x] = t;
+                __syncthreads();
+                if (part == 0 && sidx < nsum && cc < a.C) {
+                    float tot = 0.f;
+                    for (int q = 0; q < parts; ++q) tot += s_red[q * min(nsum, NT) + sidx - base];
+                    a.sums[(pass ? a.C : 0) + cc] = tot;
+                }
+            }
+            if (threadIdx.x == 0) a.counter[blockIdx.y] = 0u;          // ready for the next launch on this workspace
         }
     }
 }
@@ -748,17 +783,30 @@ static dim3 bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks, 
     else if (dtype == FS2_BF16) bn_rows_kernel<bf16_t, MODE, NT, 4><<<grid, NT, 0, stream>>>(a); \
     else { fs2_set_error("bn: dtype"); return FS2_EDTYPE; } } while (0)
 #define BN_REDUCE_BLOCKS 256       /* statistics */
+#define BN_WS_ROWS 256             /* slab rows of a workspace >= row groups of any reducing launch (<= BN_*_BLOCKS) */
+#define BN_WS_COUNTERS 64          /* arrival counters (one per channel block; C <= 1024, >= 16-channel blocks) */
+// workspace of the reducing launches: [2C reduced sums][BN_WS_COUNTERS counters][BN_WS_ROWS x 2C partial sums]
+extern "C" int fs2_bn_ws_floats(int C) { return C > 0 ? 2 * C + BN_WS_COUNTERS + BN_WS_ROWS * 2 * C : 0; }
+static int bn_ws_bind(BnArgs& a, float* ws, int C, dim3 grid) {
+    a.sums = ws;
+    a.counter = reinterpret_cast<unsigned*>(ws + 2 * C);
+    a.slab = ws + 2 * C + BN_WS_COUNTERS;
+    if (grid.x > BN_WS_ROWS || grid.y > BN_WS_COUNTERS) { fs2_set_error("bn: launch geometry %u x %u exceeds the workspace", grid.x, grid.y); return FS2_EINVAL; }
+    return FS2_OK;
+}
 #define BN_REDUCE_CBLK 64          /* channels per workgroup of the reducing modes */
 #define BN_BWD1_BLOCKS 256         /* backward sums: tanh + dropout hash per element -> needs every CU */
 
-// stats[0..C) = sum, stats[C..2C) = sum of squared deviations  (caller zeroes stats first)
+// stats[0..C) = sum, stats[C..2C) = sum of squared deviations.  `stats` is a workspace of fs2_bn_ws_floats(C) floats whose
+// counter words are zero on entry (zero the whole workspace once, when it is allocated; the kernels leave them zero).
 extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && stats, "bn_stats: null pointer");
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
-    a.x = x; a.sums = stats;
+    a.x = x;
     const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
+    if (int e = bn_ws_bind(a, stats, C, grid)) return e;
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
     else bn_stats_fix_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats, M, C);
@@ -786,8 +834,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
     (void)gamma; (void)beta;
 }
 // Train-mode statistics in two launches and no housekeeping: shifted sums (MODE 0) -> ONE kernel that converts them, updates
-// the running statistics, writes mean / rstd, counts the batch (nn.BatchNorm1d.num_batches_tracked) and CLEARS the workspace
-// for the next call (the caller zeroes it once, when it allocates it).
+// the running statistics, writes mean / rstd and counts the batch (nn.BatchNorm1d.num_batches_tracked).  The workspace
+// (fs2_bn_ws_floats(C) floats) is zeroed once by the caller, when it allocates it.
 template <typename T>
 __global__ void bn_fix_finalize_kernel(const T* __restrict__ x, float* __restrict__ stats, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_rstd,
@@ -796,7 +844,6 @@ __global__ void bn_fix_finalize_kernel(const T* __restrict__ x, float* __restric
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
     const float sh = Elem<T>::ld(x + c), s1 = stats[c], s2 = stats[C + c];
-    stats[c] = 0.f; stats[C + c] = 0.f;
     const float sum = s1 + (float)M * sh, ssd = fmaxf(s2 - s1 * s1 / (float)M, 0.f);
     const float mean = sum / (float)M, var = ssd / (float)M;
     mean_rstd[c] = mean;
@@ -812,9 +859,10 @@ extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, float* running
     FS2_CHECK_ARG(x && stats_ws && mean_rstd, "bn_train_stats: null pointer");
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_train_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
-    a.x = x; a.sums = stats_ws;
+    a.x = x;
     const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
+    if (int e = bn_ws_bind(a, stats_ws, C, grid)) return e;
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
     else bn_fix_finalize_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
@@ -849,7 +897,7 @@ extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* 
 
 // Backward, pass 1: g = dout * dropmask * act'(.)  ;  sums[c] += g, sums[C+c] += g*xhat  (also = dbeta, dgamma)
 //           pass 2: dx = gamma*rstd*(g - sums[c]/M - xhat*sums[C+c]/M)
-// sums (2C floats, zeroed by the caller) receives dbeta (first C) and dgamma (last C).
+// sums (a workspace of fs2_bn_ws_floats(C) floats, counter words zero on entry) receives dbeta (first C) and dgamma (next C).
 extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
                           float* sums, void* dx, int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev,
                           int dtype, hipStream_t stream) {
@@ -857,10 +905,11 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     FS2_CHECK_ARG(C % 4 == 0 && C <= 1024, "bn_bwd: C=%d must be a multiple of 4, <= 1024", C);
     if (M == 0) return FS2_OK;
     BnArgs a = {};
-    a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
+    a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
     int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
+    if (int e = bn_ws_bind(a, sums, C, grid)) return e;
     BN_LAUNCH(2, 1024, grid);
     vec = bn_vec(a, C, dtype);
     grid = bn_geometry(a, M, C, 256, 2048, vec);
@@ -869,21 +918,22 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     return FS2_OK;
 }
 
-// the same in two launches and no housekeeping: `sums` must be zero on entry (2C floats), `sums_next` (the workspace the NEXT
-// call will pass as `sums`) is cleared by this call, and dgamma_acc / dbeta_acc (parameter-gradient buffers) += the sums.
+// the same with the affine gradients accumulated: dgamma_acc / dbeta_acc (parameter-gradient buffers) += the reduced sums.
+// Successive calls (any width-C layer, one stream) may share one workspace.
 extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
-                              float* sums, float* sums_next, void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act,
+                              float* sums, void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act,
                               float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t stream) {
-    FS2_CHECK_ARG(x && dout && mean_rstd && gamma && beta && sums && sums_next && dx && dgamma_acc && dbeta_acc, "bn_bwd_acc: null pointer");
-    FS2_CHECK_ARG(C % 4 == 0 && C <= 1024 && sums != sums_next, "bn_bwd_acc: C=%d must be a multiple of 4, <= 1024; two distinct workspaces", C);
+    FS2_CHECK_ARG(x && dout && mean_rstd && gamma && beta && sums && dx && dgamma_acc && dbeta_acc, "bn_bwd_acc: null pointer");
+    FS2_CHECK_ARG(C % 4 == 0 && C <= 1024, "bn_bwd_acc: C=%d must be a multiple of 4, <= 1024", C);
     if (M == 0) return FS2_OK;
     BnArgs a = {};
-    a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.sums = sums; a.act = act;
+    a.x = x; a.dout = dout; a.out = dx; a.mean_rstd = mean_rstd; a.gamma = gamma; a.beta = beta; a.act = act;
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
     int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
+    if (int e = bn_ws_bind(a, sums, C, grid)) return e;
     BN_LAUNCH(2, 1024, grid);
-    a.acc_dbeta = dbeta_acc; a.acc_dgamma = dgamma_acc; a.clear = sums_next;
+    a.acc_dbeta = dbeta_acc; a.acc_dgamma = dgamma_acc;
     vec = bn_vec(a, C, dtype);
     grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(3, 256, grid);

@@ -248,12 +248,12 @@ class Engine:
 
     # ------------------------------------------------------------------ building blocks
     def _bn_workspace(self, C):
-        """[forward statistics, backward sums A, backward sums B, parity] for C channels: zeroed ONCE here, kept zero by the
-        kernels themselves (fs2_bn_train_stats / fs2_bn_bwd_acc), shared by every BatchNorm layer of that width (stream order)."""
+        """[forward statistics, backward sums] workspaces for C channels: zeroed ONCE here, kept consistent by the kernels
+        themselves (fs2_bn_train_stats / fs2_bn_bwd_acc: slab partial sums + arrival counters, bit-reproducible column sums),
+        shared by every BatchNorm layer of that width (stream order)."""
         ws = self._bn_ws.get(C)
         if ws is None:
-            z = torch.zeros(3, 2 * C, device=self.device, dtype=torch.float32)
-            ws = self._bn_ws[C] = [z[0], z[1], z[2], 0]
+            ws = self._bn_ws[C] = [ops.bn_workspace(C, self.device), ops.bn_workspace(C, self.device)]
         return ws
 
     def _bn_eval_stats(self, pre):
@@ -760,20 +760,11 @@ class Engine:
 
         # ---- postnet backward
         g = dpost
-        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         for i in reversed(range(5)):
             pre = f"postnet.convolutions.{i}."
             s = sv.pn[i]
-            ws = self._bn_workspace(s.c.shape[1])
-            k = ws[3]
-            ws[3] = 1 - k                               # ping-pong: this call reduces into ws[1+k] and clears ws[2-k] for the next one
-            if capturing:
-                # the parity above is HOST state: a captured step replays one fixed parity sequence, and a width with an odd
-                # number of BatchNorm layers (C = 80: one) would reduce into the same, never-cleared workspace on every replay.
-                # Inside a capture the target is cleared explicitly (a memset node; eager steps keep the launch-free ping-pong)
-                ws[1 + k].zero_()
             dc = ops.bn_bwd_acc(s.c, g, s.mean_rstd, P[pre + "1.weight"], P[pre + "1.bias"], s.act, sv.p_pn,
-                                _seed_pair(200 + i, seed_dev)[0], ws[1 + k], ws[2 - k], G[pre + "1.weight"], G[pre + "1.bias"],
+                                _seed_pair(200 + i, seed_dev)[0], self._bn_workspace(s.c.shape[1])[1], G[pre + "1.weight"], G[pre + "1.bias"],
                                 seed_dev=_seed_pair(200 + i, seed_dev)[1])
             self._wgrad(G[pre + "0.conv.weight"], G[pre + "0.conv.bias"], dc, s.x, T, taps=5, pad=2)
             g = self._dgemm(W, pre + "0.conv", dc, T, taps=5, pad=2, res=dpost if i == 0 else None)

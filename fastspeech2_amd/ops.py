@@ -291,7 +291,7 @@ def ln_bwd_reduce(ws, C, dgamma, dbeta):
 # ------------------------------------------------------------------ batch norm
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e-5, momentum=0.1, res=None, seed_dev=None,
                  ws=None, num_batches_tracked=None):
-    """ws: a persistent 2C-float workspace that is ZERO between calls (the kernels clear it again): statistics, running-stat
+    """ws: a persistent BN workspace (bn_workspace(C): zeroed once, kept consistent by the kernels): statistics, running-stat
     update and the num_batches_tracked increment then take two launches, with no fill / fix-up / counter launches around them."""
     M, C = x.shape
     mean_rstd = torch.empty(2 * C, device=x.device, dtype=torch.float32)
@@ -299,7 +299,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e
         _lib.call("fs2_bn_train_stats", _p(x), _p(ws), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(mean_rstd),
                   M, C, eps, momentum, dt(x), _stream())
     else:
-        stats = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+        stats = bn_workspace(C, x.device)
         _lib.call("fs2_bn_stats", _p(x), _p(stats), M, C, dt(x), _stream())
         _lib.call("fs2_bn_finalize", _p(stats), _p(running_mean), _p(running_var), _p(mean_rstd), M, C, eps, momentum,
                   _stream())
@@ -309,23 +309,27 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e
     return out, mean_rstd
 
 
-def bn_bwd_acc(x, dout, mean_rstd, gamma, beta, act, p, seed, ws, ws_next, dgamma_acc, dbeta_acc, seed_dev=None):
-    """BatchNorm backward with the affine gradients accumulated straight into dgamma_acc / dbeta_acc; ws (zero on entry) and
-    ws_next (cleared here, passed as ws by the next call) are two persistent 2C-float workspaces."""
+def bn_workspace(C, device):
+    """workspace of the reducing BatchNorm launches (per-workgroup partial sums + arrival counters): zeroed here, once"""
+    return torch.zeros(_lib.load().fs2_bn_ws_floats(C), device=device, dtype=torch.float32)
+
+
+def bn_bwd_acc(x, dout, mean_rstd, gamma, beta, act, p, seed, ws, dgamma_acc, dbeta_acc, seed_dev=None):
+    """BatchNorm backward with the affine gradients accumulated straight into dgamma_acc / dbeta_acc; ws: bn_workspace(C)."""
     M, C = x.shape
     dx = torch.empty_like(x)
-    _lib.call("fs2_bn_bwd_acc", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(ws), _p(ws_next), _p(dx), _p(dgamma_acc),
+    _lib.call("fs2_bn_bwd_acc", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(ws), _p(dx), _p(dgamma_acc),
               _p(dbeta_acc), M, C, act, p, seed, _p(seed_dev), dt(x), _stream())
     return dx
 
 
 def bn_bwd(x, dout, mean_rstd, gamma, beta, act, p, seed, seed_dev=None):
     M, C = x.shape
-    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    sums = bn_workspace(C, x.device)
     dx = torch.empty_like(x)
     _lib.call("fs2_bn_bwd", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(sums), _p(dx), M, C, act, p, seed,
               _p(seed_dev), dt(x), _stream())
-    return dx, sums[C:], sums[:C]  # dx, dgamma, dbeta
+    return dx, sums[C:2 * C], sums[:C]  # dx, dgamma, dbeta
 
 
 # ------------------------------------------------------------------ gathers

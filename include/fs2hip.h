@@ -146,9 +146,14 @@ int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_
 int fs2_ln_bwd_reduce(const float* partial_ws, int C, float* dgamma /*+=*/, float* dbeta /*+=*/, fs2_stream_t stream);
 
 /* ---- BatchNorm1d (+tanh, +dropout) of PostNet: transformer/Layers.py:129-137 ------------------------ */
-int fs2_bn_stats(const void* x, float* stats /*2C, zeroed*/, int M, int C, int dtype, fs2_stream_t stream);
-/* train-mode statistics without housekeeping launches: stats_ws (2C floats) is zero on entry and zero again on exit;
- * also updates the running statistics and increments num_batches_tracked (int64, optional) - nn.BatchNorm1d's buffers. */
+/* Column sums are bit-reproducible: every reducing launch stores per-workgroup partial sums in a workspace and the last
+ * workgroup adds them in index order (no float atomics).  A BN workspace holds fs2_bn_ws_floats(C) floats; zero it ONCE when it
+ * is allocated (its arrival counters must be zero on entry; the kernels leave them zero).  Its first 2C floats receive the sums. */
+int fs2_bn_ws_floats(int C);
+int fs2_bn_stats(const void* x, float* stats /*workspace; [0,2C) = sum | sum of squared deviations*/, int M, int C, int dtype,
+                 fs2_stream_t stream);
+/* train-mode statistics without housekeeping launches; also updates the running statistics and increments
+ * num_batches_tracked (int64, optional) - nn.BatchNorm1d's buffers. */
 int fs2_bn_train_stats(const void* x, float* stats_ws, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                        float* mean_rstd, int M, int C, float eps, float momentum, int dtype, fs2_stream_t stream);
 int fs2_bn_finalize(const float* stats, float* running_mean, float* running_var, float* mean_rstd /*2C*/, int M, int C,
@@ -158,12 +163,12 @@ int fs2_bn_finalize(const float* stats, float* running_mean, float* running_var,
 int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, const void* res, void* out,
                  int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
-               float* sums /*2C zeroed: dbeta|dgamma*/, void* dx, int M, int C, int act, float p, uint64_t seed,
+               float* sums /*workspace; [0,2C) = dbeta|dgamma*/, void* dx, int M, int C, int act, float p, uint64_t seed,
                const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
-/* the same without housekeeping launches: `sums` is zero on entry, `sums_next` (what the NEXT call passes as `sums`; a second
- * 2C-float workspace) is cleared by this call, and dgamma_acc / dbeta_acc (parameter-gradient buffers) += the reduced sums. */
+/* the same with dgamma_acc / dbeta_acc (parameter-gradient buffers) += the reduced sums; successive calls on one stream may
+ * share one workspace. */
 int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta, float* sums,
-                   float* sums_next, void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act, float p, uint64_t seed,
+                   void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act, float p, uint64_t seed,
                    const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 
 /* ---- gathers / index kernels ----------------------------------------------------------------------- */

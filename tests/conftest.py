@@ -19,3 +19,36 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------- the full-size whole-step case
+# Shared by tests/test_a_prodshape_gpu.py (fp32, elementwise - collected first) and tests/test_z_bf16_budget_gpu.py (bf16,
+# statistical bars - collected last): one fp64 oracle run of the whole train step at the bench's size per session.
+@pytest.fixture(scope="session")
+def full_case():
+    import torch
+    from oracle.weights import seeded_state_dict, synthetic_batch
+    from tests.golden import configs
+    from tests.helpers import make_model, oracle_train_case
+
+    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4, dropout=False)
+    model = make_model(pcfg, mcfg, "fp32")
+    sd = seeded_state_dict(model.state_dict(), 2025)
+    b = synthetic_batch(1234, 48, 128, dur_lo=4, dur_hi=10, min_len_frac=0.75)
+    assert b["max_mel_len"] > 850
+    oout, olosses, ograds, _ = oracle_train_case(pcfg, mcfg, sd, b, dtype=torch.float64)
+    return pcfg, mcfg, sd, b, oout, olosses, ograds
+
+
+def train_step_grads(dev, pcfg, mcfg, sd, b, cdt):
+    """one product train step (forward + loss + backward, dropout off) -> (outputs, losses, {name: fp64 gradient on the CPU})"""
+    from tests.helpers import make_model
+    from tests.test_model_gpu import run_train
+
+    model = make_model(pcfg, mcfg, cdt)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    model.disable_dropout = True
+    out, losses = run_train(model, pcfg, mcfg, b, dev)
+    grads = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None}
+    return out, losses, grads

@@ -8,9 +8,9 @@ branches.  Here:
     may differ from it by final rounding only (1 ulp = 2^-8 relative) - a wrong tap at one sequence boundary is O(1);
   * the weight-gradient kernels at M = 44 400 with ragged lens (the 5- and 8-split grids) and bf16 attention backward at
     S = 925, per-tensor;
-  * the WHOLE train step (forward + loss + backward, dropout off) at full size against the fp64 oracle: fp32 every gradient
-    tensor elementwise (<= 2e-3 of its max), bf16 per-tensor relative Frobenius error with a budget derived from bf16
-    epsilon and depth (reference model/fastspeech2.py:43-110, model/loss.py:19-92).
+  * the WHOLE train step (forward + loss + backward, dropout off) at full size against the fp64 oracle in fp32: every gradient
+    tensor elementwise (<= 2e-3 of its max) (reference model/fastspeech2.py:43-110, model/loss.py:19-92).  The bf16 whole-step
+    budget - a statistical bar, not an elementwise one - is tests/test_z_bf16_budget_gpu.py, collected last.
 """
 import math
 
@@ -19,7 +19,7 @@ import torch
 
 from oracle.weights import seeded_state_dict, synthetic_batch
 from tests.golden import configs
-from tests.helpers import bf16_matrix, make_model, oracle_train_case
+from tests.helpers import make_model
 
 pytestmark = pytest.mark.gpu
 B, L = 48, 128
@@ -562,26 +562,9 @@ def test_batchnorm_production_shape_bf16(dev, C):
 
 
 # ------------------------------------------------------------------------------------------------ whole train step
-@pytest.fixture(scope="module")
-def full_case():
-    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4, dropout=False)
-    model = make_model(pcfg, mcfg, "fp32")
-    sd = seeded_state_dict(model.state_dict(), 2025)
-    b = synthetic_batch(1234, B, L, dur_lo=4, dur_hi=10, min_len_frac=0.75)
-    assert b["max_mel_len"] > 850
-    oout, olosses, ograds, _ = oracle_train_case(pcfg, mcfg, sd, b, dtype=torch.float64)
-    return pcfg, mcfg, sd, b, oout, olosses, ograds
-
-
-def _train_step(dev, pcfg, mcfg, sd, b, cdt):
-    from tests.test_model_gpu import run_train
-    model = make_model(pcfg, mcfg, cdt)
-    model.load_state_dict(sd)
-    model.to(dev).train()
-    model.disable_dropout = True
-    out, losses = run_train(model, pcfg, mcfg, b, dev)
-    grads = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None}
-    return out, losses, grads
+# the full-size case (fp64 oracle of the whole step) lives in tests/conftest.py: the bf16 budget test, collected LAST
+# (tests/test_z_bf16_budget_gpu.py), shares it
+from tests.conftest import train_step_grads as _train_step  # noqa: E402
 
 
 def test_full_size_train_step_fp32_matches_fp64_oracle_elementwise(dev, full_case):
@@ -606,73 +589,3 @@ def test_full_size_train_step_fp32_matches_fp64_oracle_elementwise(dev, full_cas
         assert err <= 2e-3 * scale, (n, err, scale)
         fro = ((grads[n] - og).norm() / og.norm()).item()
         assert fro <= 1e-3, (n, fro)
-
-
-@pytest.fixture(scope="module")
-def full_case_bf16_weights(full_case):
-    """the same fp64 oracle run with every floating-point parameter ROUNDED to bf16 first: the bf16 engine multiplies with
-    bf16 copies of the fp32 master weights, i.e. it differentiates that slightly different network; against THIS oracle only the
-    rounding of stored activations / gradients (and fp32 accumulation) is left."""
-    pcfg, mcfg, sd, b, _, _, _ = full_case
-    sdr = {k: (v.to(torch.bfloat16).to(v.dtype) if bf16_matrix(k, v) else v) for k, v in sd.items()}
-    oout, olosses, ograds, _ = oracle_train_case(pcfg, mcfg, sdr, b, dtype=torch.float64)
-    return oout, olosses, ograds
-
-
-def test_full_size_train_step_bf16_per_tensor_budget(dev, full_case, full_case_bf16_weights):
-    """bf16 storage + bf16 MFMA (fp32 accumulate / statistics / master weights) at full size, judged against bars DERIVED from
-    bf16 itself and frozen in tests/golden/bf16_bars.json (the round-2 bars were moved four times to sit
-    above the newest measurement; these are not chosen, and are not to be edited without the table changing).
-
-    tests/golden/make_bf16_bars.py runs the fp64 oracle on the network the bf16 engine differentiates (matrices rounded to bf16)
-    twice per seed - exact, and with `oracle.storage(round_st_bf16)`, which rounds every activation the product stores between two
-    kernels (and the gradient flowing back through that edge) to bf16 - over 8 seeded (weights, batch) pairs.  That emulation's own
-    distance to the exact run is what bf16 storage costs by construction: per parameter tensor (relative Frobenius), per output
-    (valid-frame L1), per loss.  Bar of every quantity = 2 x its maximum over the seeds.  The product's distance to the same exact
-    oracle must stay below it - for EVERY tensor by name.  (The step is chaotic at its own rounding level - two
-    arithmetic-equivalent builds differ from each other by about the emulated distance, profiles/r02k_dbg_step.log - which is why
-    the comparison is to a distance, not to the emulation's values.)
-    Against the fp32-master-weight oracle (a slightly different network: the weight rounding adds its share) the numbers are
-    printed for the record only."""
-    import json
-    import os
-    bars = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bars.json")))
-    assert bars["n_seeds"] >= 8 and bars["factor"] == 2.0
-    pcfg, mcfg, sd, b, oout, olosses, ograds = full_case
-    wout, wlosses, ograds_w = full_case_bf16_weights
-    out, losses, grads = _train_step(dev, pcfg, mcfg, sd, b, "bf16")
-    assert torch.equal(out[9].cpu(), oout[9])
-    valid = (~oout[7]).unsqueeze(-1)
-    nval = valid.sum().item() * 80
-    failures = []
-    for i in (0, 1):
-        l1 = ((out[i].detach().float().cpu().double() - wout[i].detach()).abs() * valid).sum().item() / nval
-        print(f"bf16 full-size valid-frame mel L1 [{i}] = {l1:.3e}  (bar {bars['mel_l1']['bar'][i]:.3e} = 2 x emulated {bars['mel_l1']['emulated_max'][i]:.3e})")
-        if l1 > bars["mel_l1"]["bar"][i]:
-            failures.append(("mel_l1", i, l1))
-    for i, (a, o) in enumerate(zip(losses, wlosses)):
-        rel = abs(a.item() - o.item()) / max(1.0, abs(o.item()))
-        if rel > bars["loss_rel"]["bar"][i]:
-            failures.append(("loss", i, rel, bars["loss_rel"]["bar"][i]))
-    gmax = max(g.abs().max().item() for g in ograds.values())
-    worst, ratios = [], []
-    for n, og in ograds_w.items():
-        if ograds[n].abs().max().item() < 1e-9 * gmax:   # true gradient zero (w_ks.bias, conv biases in front of BatchNorm): noise only
-            if grads[n].abs().max().item() > 1e-3 * gmax:
-                failures.append((n, "zero-gradient tensor", grads[n].abs().max().item()))
-            continue
-        fro = ((grads[n] - og).norm() / og.norm()).item()
-        bar = bars["grad"][n]["bar"]
-        worst.append((fro, n))
-        ratios.append((fro / bars["grad"][n]["emulated_max"], n))
-        if fro > bar:
-            failures.append((n, fro, bar))
-    worst.sort(reverse=True)
-    ratios.sort(reverse=True)
-    big = sorted(f for f, n in worst if ograds_w[n].numel() > 1024)
-    print(f"bf16 full-size per-tensor relative Frobenius error vs the fp64 oracle with bf16-rounded weights: weight tensors median "
-          f"{big[len(big) // 2]:.2e} max {big[-1]:.2e}; worst 6: {[(f'{f:.2e}', n) for f, n in worst[:6]]}")
-    print(f"largest product / emulated ratios (bar at 2.0): {[(f'{r:.2f}', n) for r, n in ratios[:8]]}")
-    fm = sorted(((grads[n] - og).norm() / og.norm()).item() for n, og in ograds.items() if og.abs().max().item() >= 1e-9 * gmax and og.numel() > 1024)
-    print(f"for the record, vs the fp32-master-weight oracle (adds the weight rounding): weight tensors median {fm[len(fm) // 2]:.2e} max {fm[-1]:.2e}")
-    assert not failures, failures
