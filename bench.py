@@ -181,7 +181,7 @@ def capture_graph(model, opt, fwd_bwd):
     # capture, replays came out with gradients 2.8e-3 (relative, Adam first moments after 4 replays) away from the eager steps
     # (tests/test_graph_gpu.py, round 3; single-stream capture matches to 1e-6), and the forked capture was also the slowest
     # variant (16.9 ms vs 11.6 single-stream vs 9.3 eager with the side stream) - so the graph path does not fork.
-    model._engine.use_side_stream = False
+    # (Engine._side_begin enforces that itself while a capture is in progress; the caller's setting is left as it was)
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad()
     torch.cuda.synchronize()
@@ -305,7 +305,8 @@ def synth_cpu_baseline(args, lens8, threads):
 
 
 SYNTH_NAMES = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel",
-               5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)", 7: "conv_gemm_w_kernel (taps == 1, N % 256 == 0)"}
+               5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)", 7: "conv_gemm_w_kernel (taps == 1, N % 256 == 0)",
+               8: "conv_gemm_t_kernel (taps >= 3, 512x128 tiles)"}
 
 
 def synth_measure(args, device, rank, world, steps, warmup, want_roofline):

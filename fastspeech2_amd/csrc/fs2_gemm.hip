@@ -953,8 +953,11 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
 // Which kernel a launch description dispatches to: a PURE function of the description (no state, no environment in the
 // shipped build), shared by fs2_conv_gemm and by the query entry point fs2_conv_gemm_variant that bench.py uses to attribute
 // its HIP-event durations to the kernel names rocprofv3 reports.
+// defined in fs2_gemm_t.hip
+bool fs2_conv_gemm_t_ok(const ConvGemmArgs& a, bool has_map, int dtype, bool have_tail_ws);
+void fs2_conv_gemm_t_launch(const ConvGemmArgs& a, hipStream_t stream, float* tail_ws);
 struct GemmPick { int variant; bool ring_inact, ks2; };
-static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map) {
+static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, bool has_tail_ws = true) {
     const int M = a.M, N = a.N, Cin = a.Cin, taps = a.taps, dil = a.dil, in_act = a.in_act;
     GemmPick p;
     const long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
@@ -986,6 +989,8 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map) {
     // wide-tile one-tap kernel (fs2_gemm_w.hip): N a multiple of 256 - the Linear layers of the FFT blocks and their data gradients
     static const int w_on = fs2_dev_env("FS2_GEMM_W", 1);
     if (w_on && !skinny && fs2_conv_gemm_w_ok(a, has_map, dtype)) { p.variant = FS2_GEMM_WIDE_1TAP; return p; }
+    // tall-tile all-consumer kernel (fs2_gemm_t.hip): the large convolutions without lens, when its 512-row tiles fill the chip
+    if (!skinny && fs2_conv_gemm_t_ok(a, has_map, dtype, has_tail_ws)) { p.variant = FS2_GEMM_TALL; return p; }
     p.variant = skinny ? FS2_GEMM_SKINNY : (persist ? (taps == 1 ? FS2_GEMM_PERSIST_1TAP : FS2_GEMM_PERSIST) : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN)));
     return p;
 }
@@ -1029,8 +1034,10 @@ static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* b
     a.dbg = gemm_dbg;
     const long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
-    const GemmPick pk = conv_gemm_pick(a, dtype, tile_map != nullptr);
-    if (pk.variant == FS2_GEMM_SKINNY) {
+    const GemmPick pk = conv_gemm_pick(a, dtype, tile_map != nullptr, tail_ws != nullptr);
+    if (pk.variant == FS2_GEMM_TALL) {
+        fs2_conv_gemm_t_launch(a, stream, tail_ws);
+    } else if (pk.variant == FS2_GEMM_SKINNY) {
         if (Cin == 32) launch_skinny<32>(a, stream);
         else if (Cin == 64) launch_skinny<64>(a, stream);
         else launch_skinny<128>(a, stream);

@@ -199,7 +199,7 @@ class Engine:
                 self.lp_synced = True
             if need_dgrad:
                 # the data-gradient packs are first read in BACKWARD: pack them on the side stream, off the forward chain
-                if self.use_side_stream:
+                if self.use_side_stream and not torch.cuda.is_current_stream_capturing():
                     if self._side_stream is None:
                         self._side_stream = torch.cuda.Stream(device=self.device)
                     cur = torch.cuda.current_stream()
@@ -264,6 +264,10 @@ class Engine:
         Was three tiny torch launches (add, rsqrt, cat) per PostNet layer and synthesis batch - 15 of a synthesis step's launches."""
         rm, rv = self.Bf[pre + "1.running_mean"], self.Bf[pre + "1.running_var"]
         key = (rm.data_ptr(), rm._version, rv.data_ptr(), rv._version)
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a tensor made inside a capture lives in the graph's pool and holds nothing until a replay: never cache it, and never
+            # hand a captured graph a cached tensor whose key could go stale between replays
+            return torch.cat([rm, torch.rsqrt(rv + 1e-5)])
         hit = self._bn_eval.get(pre)
         if hit is None or hit[0] != key:
             hit = (key, torch.cat([rm, torch.rsqrt(rv + 1e-5)]))
@@ -380,6 +384,8 @@ class Engine:
         """side stream available for branch concurrency (creates it)"""
         if not (self.use_side_stream and self.concurrent_branches) or self.device.type != "cuda":
             return False
+        if torch.cuda.is_current_stream_capturing():        # one stream inside a capture (see _side_begin)
+            return False
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         self._branch_main = torch.cuda.current_stream()
@@ -426,7 +432,9 @@ class Engine:
         if self._pack_pending:                  # data-gradient packs were written on the side stream during forward
             self._main.wait_stream(self._side_stream)
             self._pack_pending = False
-        if not self.use_side_stream:
+        if not self.use_side_stream or torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture the step stays on ONE stream whatever use_side_stream says: a forked capture replayed
+            # with gradients 2.8e-3 away from the eager steps (round 3, cause not found) and was the slowest variant anyway
             self._side = None
             return
         if self._side_stream is None:

@@ -54,6 +54,10 @@ def load_checkpoint(path):
     except ImportError:                                 # which numpy 2 resolves to the same objects)
         from numpy.core import multiarray as _ma
     allow += [_ma.scalar, _ma._reconstruct]
+    # torch matches allow-listed globals by "module.qualname" STRING: under numpy 2 the two objects above are named
+    # numpy._core.multiarray.*, while a checkpoint pickled with numpy 1.x - every checkpoint the reference's authors published -
+    # names numpy.core.multiarray.*.  The tuple form registers the same objects under the legacy names too.
+    allow += [(_ma.scalar, "numpy.core.multiarray.scalar"), (_ma._reconstruct, "numpy.core.multiarray._reconstruct")]
     allow += [type(_np.dtype(t)) for t in ("float64", "float32", "int64", "int32")]
     with torch.serialization.safe_globals(allow):
         return torch.load(path, map_location="cpu", weights_only=True)

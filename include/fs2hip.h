@@ -84,6 +84,8 @@ int fs2_conv_gemm_splitk(const void* X, long ldx, const void* Wpacked, const flo
 #define FS2_GEMM_PERSIST 5 /* conv_gemm_p_kernel<false>: persistent 256x128 convolution (taps >= 3), MFMA-bound */
 #define FS2_GEMM_PERSIST_1TAP 6 /* conv_gemm_p_kernel<true>: the same kernel for taps == 1 (Linear / k=1 conv): HBM-bound at K <= 1024 */
 #define FS2_GEMM_WIDE_1TAP 7 /* conv_gemm_w_kernel: persistent 256x256 tiles, every wave loads and multiplies (taps == 1, N % 256 == 0) */
+#define FS2_GEMM_TALL 8    /* conv_gemm_t_kernel: persistent 512x128 tiles, eight self-loading consumer waves (taps >= 3, no lens; a
+                              tail workspace is assumed present, as the engine always passes one) */
 int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens, int has_map, int M, int N, int Cin, int S, int taps,
                           int dil, int in_act, float in_slope, int dtype);
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):

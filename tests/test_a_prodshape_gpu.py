@@ -124,6 +124,51 @@ def test_contraction_forward_and_dgrad_production_shapes(dev, dtype, name, Cin, 
             assert_rounding_only(yq, ref_l[:Mq], dtype, (name, "fwd tail sweep", nb))
 
 
+@pytest.mark.parametrize("name,Cin,Cout,k", [("ffn w_1 k9", 256, 1024, 9), ("postnet k5", 512, 512, 5), ("k9 C512", 512, 512, 9)])
+def test_tall_tile_kernel_without_lens(dev, name, Cin, Cout, k):
+    """conv_gemm_t_kernel (fs2_gemm_t.hip: 512 x 128 tiles, eight self-loading consumer waves, half-chunk K loop) takes the large
+    convolutions that carry no lens - what the LJSpeech bench step launches.  Every batch size below changes the tile count (whole
+    rounds, 2- / 4-way tail parts, a last M-tile with rows beyond M), sequences end inside tiles (tap masks at both ends of
+    every sequence), and the epilogue variants are the ones the engine uses: bias + ReLU, residual add, ReLU gate, accumulate +
+    scale.  Elementwise against the exact-product reference, rounding only."""
+    ops = _ops()
+    from fastspeech2_amd import _lib
+    S, dtype = 925, torch.bfloat16
+    g = torch.Generator().manual_seed(sum(ord(c) for c in name) + 1)
+    pad = (k - 1) // 2
+    x = torch.randn(B * S, Cin, generator=g).to(dev).to(dtype)
+    w = (torch.randn(Cout, k, Cin, generator=g) / math.sqrt(Cin * k)).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    wf, wd = ops.pack_weight(w, dtype)
+    ref = conv_ref_gpu(x, wf, bias, S, pad)
+    tws = ops.tail_workspace(dev).fill_(float("nan"))
+    var = _lib.load().fs2_conv_gemm_variant(Cin, Cout, 0, 0, 0, B * S, Cout, Cin, S, k, 1, 0, 0.0, 1)
+    assert var == 8, var                                                          # FS2_GEMM_TALL at the full batch
+    seen = 0
+    for nb in (48, 45, 41, 37, 30, 24, 19):
+        Mq = nb * S
+        if _lib.load().fs2_conv_gemm_variant(Cin, Cout, 0, 0, 0, Mq, Cout, Cin, S, k, 1, 0, 0.0, 1) != 8:
+            continue
+        seen += 1
+        for tail in (tws, None):
+            y = ops.conv_gemm(x[:Mq], wf, bias, S, taps=k, pad=pad, act=ops.ACT_RELU, tail_ws=tail)
+            assert_rounding_only(y, torch.relu(ref[:Mq]), dtype, (name, "fwd", nb, tail is not None))
+    assert seen >= 2
+    # data gradient forms (tap-flipped pack) at the full batch: residual add, ReLU gate, accumulate with scale
+    dy = torch.randn(B * S, Cout, generator=g).to(dev).to(dtype)
+    res = torch.randn(B * S, Cin, generator=g).to(dev).to(dtype)
+    if _lib.load().fs2_conv_gemm_variant(Cout, Cin, Cin, 0, 0, B * S, Cin, Cout, S, k, 1, 0, 0.0, 1) == 8:
+        dref = conv_ref_gpu(dy, wd, None, S, (k - 1) - pad)
+        dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, res=res, tail_ws=tws)
+        assert_rounding_only(dx, dref + res.double(), dtype, (name, "dgrad+res"))
+        dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, act=ops.ACT_GATE, res=res, tail_ws=tws)
+        assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)), dtype, (name, "dgrad gate"))
+    acc0 = torch.randn(B * S, Cout, generator=g).to(dev).to(dtype)
+    out = acc0.clone()
+    ops.conv_gemm(x, wf, bias, S, taps=k, pad=pad, out=out, accumulate=True, out_scale=0.5, tail_ws=tws)
+    assert_rounding_only(out, acc0.double() + 0.5 * ref, dtype, (name, "accumulate"))
+
+
 @pytest.mark.parametrize("name,C,N,k,dil,S,Bq", [("rb C256 k7 d3", 256, 256, 7, 3, 7200, 8), ("rb C128 k11 d5", 128, 128, 11, 5, 57600, 4),
                                                  ("rb C128 k3 d1", 128, 128, 3, 1, 57600, 4), ("rb C256 k11 d1", 256, 256, 11, 1, 7200, 8),
                                                  ("up0 as 3-tap", 512, 2048, 3, 1, 900, 8)])

@@ -136,3 +136,30 @@ def test_oracle_written_checkpoint_matches_reference_checksums(tmp_path):
         assert abs(got[1] - ref[1]) <= 2e-4 * ref[1] + 1e-12, (k, got, ref)           # abs-sum
     assert float(next(iter(ock["optimizer"]["state"].values()))["step"]) == float(g["adam_step"]) == 2.0
     assert abs(ock["optimizer"]["param_groups"][0]["lr"] - float(g["lr_in_ckpt"])) <= 1e-12
+
+
+def test_numpy1_named_pickle_loads_through_the_safe_unpickler(tmp_path):
+    """The authors' published checkpoints were pickled with numpy 1.x: the learning-rate scalar is reconstructed through
+    `numpy.core.multiarray.scalar`, a NAME numpy 2 no longer uses for the same object (torch's weights_only allow-list matches by
+    name).  Rewrite a fresh checkpoint's pickle to the legacy module name and load it through load_checkpoint."""
+    import zipfile
+    from fastspeech2_amd.utils import load_checkpoint
+    src, dst = str(tmp_path / "new.pth.tar"), str(tmp_path / "legacy.pth.tar")
+    lr = np.power(256.0, -0.5) * np.float64(0.25)                     # a numpy scalar, as model/optimizer.py:19,50 leaves in the state
+    torch.save({"model": {"w": torch.arange(6.0).view(2, 3)}, "optimizer": {"state": {}, "param_groups": [{"lr": lr, "betas": (0.9, 0.98)}]}}, src)
+    new, old = b"numpy._core.multiarray", b"numpy.core.multiarray"
+    n = 0
+    with zipfile.ZipFile(src) as zi, zipfile.ZipFile(dst, "w", zipfile.ZIP_STORED) as zo:
+        for item in zi.infolist():
+            data = zi.read(item.filename)
+            if item.filename.endswith("data.pkl") and new in data:
+                # protocol-2 GLOBAL opcode: 'c' module '\n' name '\n' - plain text, so the shorter legacy name drops in byte for byte
+                n += data.count(new)
+                data = data.replace(new, old)
+            zo.writestr(item, data)
+    if np.lib.NumpyVersion(np.__version__) >= "2.0.0":
+        assert n >= 1, "the pickle was expected to name numpy._core.multiarray"
+    ck = load_checkpoint(dst)
+    assert float(ck["optimizer"]["param_groups"][0]["lr"]) == float(lr)
+    assert torch.equal(ck["model"]["w"], torch.arange(6.0).view(2, 3))
+    assert float(load_checkpoint(src)["optimizer"]["param_groups"][0]["lr"]) == float(lr)

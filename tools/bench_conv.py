@@ -20,8 +20,11 @@ SHAPES = [("ffn k9 fwd+relu", 256, 1024, 9, False, ops.ACT_RELU, True), ("ffn k9
           ("ffn k9 dgrad+res", 1024, 256, 9, True, ops.ACT_NONE, True), ("ffn k9 dgrad+res (no lens)", 1024, 256, 9, True, ops.ACT_NONE, False),
           ("postnet k5 fwd", 512, 512, 5, False, ops.ACT_NONE, False), ("postnet k5 dgrad", 512, 512, 5, False, ops.ACT_NONE, False),
           ("postnet k5 80->512", 80, 512, 5, False, ops.ACT_NONE, False), ("postnet k5 512->80", 512, 80, 5, False, ops.ACT_NONE, False),
-          ("pred k3 256->256", 256, 256, 3, False, ops.ACT_RELU, False)]
+          ("pred k3 256->256", 256, 256, 3, False, ops.ACT_RELU, False), ("k9 512->512", 512, 512, 9, False, ops.ACT_RELU, False)]
+ONLY = os.environ.get('BENCH_ONLY')
 for name, K, N, taps, res, act, use_lens in SHAPES:
+    if ONLY and not any(t in name for t in ONLY.split(',')):
+        continue
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, taps, K, device=dev) / math.sqrt(K * taps)).to(torch.bfloat16)
     bias = torch.randn(N, device=dev) if "fwd" in name else None
@@ -42,4 +45,5 @@ for name, K, N, taps, res, act, use_lens in SHAPES:
         ts.append(e0.elapsed_time(e1) / 10)
     ms = sorted(ts)[2]
     rows = valid if use_lens else M
-    print(f"  {name:28s} Cin={K:4d} N={N:4d} taps {taps}: {ms * 1e3:7.1f} us  {2.0 * rows * K * taps * N / ms / 1e9:7.1f} TF (valid rows {rows})", flush=True)
+    var = _lib.load().fs2_conv_gemm_variant(K, N, N if res else 0, int(use_lens), int(use_lens), M, N, K, S, taps, 1, 0, 0.0, 1)
+    print(f"  {name:28s} variant {var} Cin={K:4d} N={N:4d} taps {taps}: {ms * 1e3:7.1f} us  {2.0 * rows * K * taps * N / ms / 1e9:7.1f} TF (valid rows {rows})", flush=True)
