@@ -8,15 +8,10 @@
 //     N-tile: L2 -> LDS bytes per MFLOP ~ 1 / (taps N_t) + 1 / M_t, and at M_t = 256 the weight term is 4/5 of it; its r02 ablation
 //     says the same - loaders + barriers alone 97 us of a 215 us launch whose MFMA floor is 105 us.  Here M_t = 512: the weight
 //     stream is shared by twice the rows (k = 9: -41 % operand bytes per FLOP, DMA floor 97 -> 57 us).
-//   * FOUR waves, one per SIMD with the whole 512-register file, each owning 128 (M) x 128 (N) of the 512 x 128 tile: 8
-//     ds_read_b128 per 16 MFMAs (0.5 per MFMA; the 64 x 128 wave tile of fs2_gemm_p.hip needs 0.75), 32 MFMAs between barriers,
-//     every wave issues its own share of the LDS-DMA (the structure of fs2_wgrad.hip): no loader waves.  Two 8-wave forms were
-//     measured first (git history, profiles/r04{j,k,l}_tall_ablation.log): two 64 x 128 waves per SIMD, both interleaving reads with
-//     MFMAs (205 us on the k = 9 FFN forward; 197 for fs2_gemm_p.hip) and the same waves in compute / load ping-pong (213 us).
-//     Their ablations: MFMAs + barriers alone 133 us (the chip clocks to ~1.95 GHz under this load: 115 us would be the pipe's
-//     floor, not 93), + fragment reads +34, + DMA issue +20, + epilogue +29 - reads and DMA issue did not hide under the partner
-//     wave's MFMAs (a load phase of 12 reads + 1.5 DMA pieces is longer than a 16-MFMA compute phase).  Fewer reads per MFMA and
-//     twice the MFMAs per barrier is what is left.
+//   * one consumer wave per SIMD issues reads and MFMAs in order and nothing runs while it waits.  Here EIGHT waves, two per
+//     SIMD, each owning 64 (M) x 128 (N) of the 512 x 128 tile - same fragment traffic per MFMA (6 ds_read_b128 per 8 MFMAs,
+//     37 % of the LDS pipe at gfx950's 4 cycles per ds_read_b128) - and every wave issues its own share of the LDS-DMA (the
+//     structure of fs2_wgrad.hip): no loader waves, 256 registers per wave.
 //   * LDS: a 528-row halo tile at 64 channels would be 67.6 KB per buffer and could not be double-buffered next to a weight ring,
 //     so the K loop walks HALF chunks of 32 channels: activation halo tile [528][32] (33 KB) x 2 buffers (buffer = half h), weight
 //     ring of TAPS [128][32] slots (slot = tap; 8 KB each: exactly one 1 KiB DMA piece per wave and K-step).  Rows are 64 bytes;
@@ -114,11 +109,11 @@ __device__ __forceinline__ void t_epilogue_part(float* slab, f32x16 (&acc)[2][4]
 
 // ABL (dev builds): 1 = no DMA, 2 = no MFMA, 4 = no fragment reads, 8 = no per-step barrier (only with 1), 16 = no epilogue
 template <int TAPS, int ABL>
-__global__ void __launch_bounds__(256) conv_gemm_t_kernel(ConvGemmArgs a, PSched sc0) {
+__global__ void __launch_bounds__(512) conv_gemm_t_kernel(ConvGemmArgs a, PSched sc0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef TCfg<TAPS> C;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // rows 128 wave .. of the tile
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = wm: rows 64 wave .. of the tile
     PSched sc = sc0;
     sc.b = blockIdx.x;
     const int ntiles = t_ntiles(sc);
@@ -137,63 +132,57 @@ __global__ void __launch_bounds__(256) conv_gemm_t_kernel(ConvGemmArgs a, PSched
     int prow = lane >> 2;
     const unsigned pchunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     const unsigned ldx2 = (unsigned)(a.ldx * 2), ldw2 = (unsigned)(a.ldw * 2), cin2 = (unsigned)(a.Cin * 2);
-    const unsigned adst = smem_u + (unsigned)(wave * 1024);              // + buffer * A_BYTES + i * 4096: piece i of this wave
-    const unsigned bdst = smem_u + (unsigned)(T_B_OFF + wave * 2048);    // + slot * B_BYTES (+ 1024: the wave's second piece)
+    const unsigned adst = smem_u + (unsigned)(wave * 1024);              // + buffer * A_BYTES + i * 8192: piece i of this wave
+    const unsigned bdst = smem_u + (unsigned)(T_B_OFF + wave * 1024);    // + slot * B_BYTES
     // the chunk being multiplied (cur) and the one after it (nxt: the next 64 channels of the unit, the first chunk of the
     // workgroup's next unit, or - past the end - the current one again)
     const unsigned char *xcur, *wcur, *xnxt, *wnxt;
     int m0cur, m0nxt, nk = 0, nc = 0, nkc_n;
-    unsigned offB, offBn, offB2, offBn2;                                 // the wave's two weight pieces: rows 32 wave .., 32 wave + 16 ..
-    auto unit_origin = [&](int k, int& m0, const unsigned char*& xp, const unsigned char*& wp, unsigned& ob, unsigned& ob2) {
+    unsigned offB, offBn;
+    auto unit_origin = [&](int k, int& m0, const unsigned char*& xp, const unsigned char*& wp, unsigned& ob) {
         int mt, nt, kc0, np;
         t_tile_of(k, units, mt, nt, kc0, np);
         m0 = mt * T_TM;
         xp = Xb + (size_t)kc0 * 128;
         wp = Wb + (size_t)kc0 * 128;
-        ob = (unsigned)min(nt * 128 + wave * 32 + prow, a.N - 1) * ldw2 + pchunk;
-        ob2 = (unsigned)min(nt * 128 + wave * 32 + 16 + prow, a.N - 1) * ldw2 + pchunk;
+        ob = (unsigned)min(nt * 128 + wave * 16 + prow, a.N - 1) * ldw2 + pchunk;
     };
-    unit_origin(0, m0cur, xcur, wcur, offB, offB2);
+    unit_origin(0, m0cur, xcur, wcur, offB);
     nkc_n = (ntiles == 1) ? nkc_last : nkc;
-    xnxt = xcur; wnxt = wcur; m0nxt = m0cur; offBn = offB; offBn2 = offB2;
+    xnxt = xcur; wnxt = wcur; m0nxt = m0cur; offBn = offB;
 #define T_ADVANCE_NEXT()                                                                                                    \
     do {                                                                                                                    \
         if (nc + 1 < nkc_n) { ++nc; xnxt += 128; wnxt += 128; }                                                             \
-        else if (nk + 1 < ntiles) { ++nk; nc = 0; nkc_n = (nk == ntiles - 1) ? nkc_last : nkc; unit_origin(nk, m0nxt, xnxt, wnxt, offBn, offBn2); } \
+        else if (nk + 1 < ntiles) { ++nk; nc = 0; nkc_n = (nk == ntiles - 1) ? nkc_last : nkc; unit_origin(nk, m0nxt, xnxt, wnxt, offBn); } \
     } while (0)
     T_ADVANCE_NEXT();
-    // piece I (0 .. 8) of the halo tile whose rows start at tile origin M0_, channels at XP: tile rows 16 (wave + 4 I) .. ; piece 8
-    // exists for wave 0 only (rows 512 .. 527) - the other waves re-issue their piece 7 so that every wave issues the same count
+    // piece I (0 .. 4) of the halo tile whose rows start at tile origin M0_, channels at XP: tile rows 16 (wave + 8 I) .. ; piece 4
+    // exists for wave 0 only (rows 512 .. 527) - the other waves re-issue their piece 3 so that every wave issues the same count
 #define T_ISSUE_A(M0_, XP, BUF, I)                                                                                          \
     do {                                                                                                                    \
         if (!(ABL & 1)) {                                                                                                   \
-            const int i_ = ((I) == 8 && wave != 0) ? 7 : (I);                                                               \
-            asm volatile("" : "+v"(prow));                  /* (opaque: hoisted per-piece row offsets get spilled, and a scratch reload waits on vmcnt(0)) */ \
-            const int g_ = min(max((M0_) - a.pad + (wave + 4 * i_) * 16 + prow, 0), a.M - 1);                               \
-            t_glds((unsigned)g_ * ldx2 + pchunk, (XP), adst + (unsigned)((BUF) * T_A_BYTES + i_ * 4096));                   \
+            const int i_ = ((I) == 4 && wave != 0) ? 3 : (I);                                                               \
+            asm volatile("" : "+v"(prow));                  /* (opaque: five hoisted row offsets were spilled, and a scratch reload waits on vmcnt(0)) */ \
+            const int g_ = min(max((M0_) - a.pad + (wave + 8 * i_) * 16 + prow, 0), a.M - 1);                               \
+            t_glds((unsigned)g_ * ldx2 + pchunk, (XP), adst + (unsigned)((BUF) * T_A_BYTES + i_ * 8192));                   \
         }                                                                                                                   \
     } while (0)
-#define T_ISSUE_B(WP, OFFB, OFFB2, TAP)                                                                                     \
-    do {                                                                                                                    \
-        if (!(ABL & 1)) {                                                                                                   \
-            t_glds((OFFB), (WP) + (size_t)(TAP) * cin2, bdst + (unsigned)((TAP) * T_B_BYTES));                              \
-            t_glds((OFFB2), (WP) + (size_t)(TAP) * cin2, bdst + (unsigned)((TAP) * T_B_BYTES + 1024));                      \
-        }                                                                                                                   \
-    } while (0)
+#define T_ISSUE_B(WP, OFFB, TAP)                                                                                            \
+    do { if (!(ABL & 1)) t_glds((OFFB), (WP) + (size_t)(TAP) * cin2, bdst + (unsigned)((TAP) * T_B_BYTES)); } while (0)
 
     // prologue: both halo tiles of the first chunk, the weight slots of its first half
 #pragma unroll
-    for (int i = 0; i < 9; ++i) T_ISSUE_A(m0cur, xcur, 0, i);
+    for (int i = 0; i < 5; ++i) T_ISSUE_A(m0cur, xcur, 0, i);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) T_ISSUE_A(m0cur, xcur + 64, 1, i);
+    for (int i = 0; i < 5; ++i) T_ISSUE_A(m0cur, xcur + 64, 1, i);
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) T_ISSUE_B(wcur, offB, offB2, t);
+    for (int t = 0; t < TAPS; ++t) T_ISSUE_B(wcur, offB, t);
 
     // ------------------------------------------------------------------ MFMA side
     const int fl = lane & 31, fh = lane >> 5;
     // per-lane LDS addresses.  A: row base + (((2 s + fh) ^ key(tap)) << 4), key(tap) = ((fl + tap) >> 2) & 3 (dil = 1): the keys of
     // all taps packed two bits each; buffer, tap shift and the second 32-row block are immediates.  B: the key never changes.
-    const unsigned alane = smem_u + (unsigned)((wave * 128 + fl) * 64);
+    const unsigned alane = smem_u + (unsigned)((wave * 64 + fl) * 64);
     unsigned kpack = 0;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) kpack |= (unsigned)(((fl + t) >> 2) & 3) << (2 * t);
@@ -205,103 +194,111 @@ __global__ void __launch_bounds__(256) conv_gemm_t_kernel(ConvGemmArgs a, PSched
 #define T_A_OFF(H_, T_) ((H_) * T_A_BYTES + (T_) * 64)
 #define T_B_OFFS(T_) (((T_) >= 4 ? (T_) - 4 : (T_)) * T_B_BYTES)
 
-    u32x4 Af[2][4], Bf[2][4];                                // [set][mb], [set][nb]: fragment double buffer
-    f32x16 acc[4][4];                                        // 256 registers: one wave per SIMD owns the whole file
+    u32x4 Af[2][2], Bf[2][4];                                // [k-slice][mb], [k-slice][nb]: all twelve fragments of one K-step
+    f32x16 acc[2][4];
 #define FS2T_DS_READ(dst, addr, OFF)                                                                                        \
     do {                                                                                                                    \
         if (!(ABL & 4)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));                  \
         else asm volatile("" : "=v"(dst));                                                                                  \
     } while (0)
-#define FS2T_MFMA(SET, MB, NB, AV)                                                                                          \
-    do { if (!(ABL & 2)) acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bf[SET][NB]),     \
+#define FS2T_MFMA(S_, MB, NB, AV)                                                                                           \
+    do { if (!(ABL & 2)) acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bf[S_][NB]),      \
                                                                            __builtin_bit_cast(bf16x8, AV), acc[MB][NB], 0, 0, 0); } while (0)
-#define T_LGKM(N) do { if (!(ABL & 32)) FS2T_WAIT_LGKM(N); } while (0)
-    // one k-slice: 16 MFMAs on fragment set SET (4 row blocks x 4 column blocks), the eight reads of the next slice into set
-    // SET^1, one behind each of the first eight MFMAs in the order A0 B0 B1 B2 B3 A1 A2 A3 - the order the MFMAs need them in.
-    // Counted lgkmcnt: the previous slice left eight reads in flight; the first MFMA needs two of them (<= 6 left), each of the next
-    // four one more while one new read goes out per MFMA (<= 6), row block 2 / 3 start with ten / nine in flight (<= 9 / <= 8).
-#define T_ROWMASK(MB, LIVE) (MASKED && !(LIVE) ? u32x4{0u, 0u, 0u, 0u} : Af[SET_][MB])
-#define FS2T_SLICE(SET, MASKED_, L0, L1, L2, L3, AADDR, AOFF, BADDR, BOFF)                                                  \
+    // PING-PONG (MI355X_MICROARCH.md "Two waves per SIMD"): the matrix pipe is per SIMD and fully paced - a wave cannot slip an
+    // MFMA into a gap shorter than 32 cycles, so two waves that both interleave reads with their MFMAs fragment each other's
+    // stream (the previous version of this loop: 1 408 cycles per step for 1 024 of MFMA work with every wait removed).  Here
+    // the two waves of a SIMD alternate roles phase by phase, one barrier per phase:
+    //   COMPUTE(step)  16 MFMAs back to back on the twelve fragments the wave loaded in its previous phase;
+    //   LOAD(step)     the wave's DMA pieces (the refill of the slot everybody has just left, halo pieces at taps 0 / 1), then the
+    //                  twelve fragment reads of `step`, landed (lgkmcnt(0)) before the barrier.
+    // Waves 0-3 run COMPUTE(i) | LOAD(i+1), waves 4-7 LOAD(i) | COMPUTE(i): in every phase one wave of each SIMD multiplies while
+    // the other loads.  Slot (half, tap) is read in the phase before the first group's COMPUTE and in the next one, and refilled -
+    // with the same tap of the NEXT half chunk - from the LOAD that follows.
+#define T_COMPUTE(T, MASKED)                                                                                                \
     do {                                                                                                                    \
-        constexpr int SET_ = (SET); constexpr bool MASKED = (MASKED_);                                                       \
-        u32x4 av_;                                                                                                          \
-        const unsigned aa_ = (AADDR), ba_ = (BADDR);                                                                        \
-        T_LGKM(6); FS2T_FENCE();                                                                                            \
-        av_ = T_ROWMASK(0, L0);                                                                                             \
-        FS2T_MFMA(SET, 0, 0, av_); FS2T_FENCE(); FS2T_DS_READ(Af[SET ^ 1][0], aa_, (AOFF)); FS2T_FENCE();                   \
-        T_LGKM(6); FS2T_FENCE();                                                                                            \
-        FS2T_MFMA(SET, 0, 1, av_); FS2T_FENCE(); FS2T_DS_READ(Bf[SET ^ 1][0], ba_, (BOFF)); FS2T_FENCE();                   \
-        T_LGKM(6); FS2T_FENCE();                                                                                            \
-        FS2T_MFMA(SET, 0, 2, av_); FS2T_FENCE(); FS2T_DS_READ(Bf[SET ^ 1][1], ba_, (BOFF) + 2048); FS2T_FENCE();            \
-        T_LGKM(6); FS2T_FENCE();                                                                                            \
-        FS2T_MFMA(SET, 0, 3, av_); FS2T_FENCE(); FS2T_DS_READ(Bf[SET ^ 1][2], ba_, (BOFF) + 4096); FS2T_FENCE();            \
-        T_LGKM(6); FS2T_FENCE();                                                                                            \
-        av_ = T_ROWMASK(1, L1);                                                                                             \
-        FS2T_MFMA(SET, 1, 0, av_); FS2T_FENCE(); FS2T_DS_READ(Bf[SET ^ 1][3], ba_, (BOFF) + 6144); FS2T_FENCE();            \
-        FS2T_MFMA(SET, 1, 1, av_); FS2T_FENCE(); FS2T_DS_READ(Af[SET ^ 1][1], aa_, (AOFF) + 2048); FS2T_FENCE();            \
-        FS2T_MFMA(SET, 1, 2, av_); FS2T_FENCE(); FS2T_DS_READ(Af[SET ^ 1][2], aa_, (AOFF) + 4096); FS2T_FENCE();            \
-        FS2T_MFMA(SET, 1, 3, av_); FS2T_FENCE(); FS2T_DS_READ(Af[SET ^ 1][3], aa_, (AOFF) + 6144); FS2T_FENCE();            \
-        T_LGKM(9); FS2T_FENCE();                                                                                            \
-        av_ = T_ROWMASK(2, L2);                                                                                             \
-        FS2T_MFMA(SET, 2, 0, av_); FS2T_MFMA(SET, 2, 1, av_); FS2T_MFMA(SET, 2, 2, av_); FS2T_MFMA(SET, 2, 3, av_); FS2T_FENCE(); \
-        T_LGKM(8); FS2T_FENCE();                                                                                            \
-        av_ = T_ROWMASK(3, L3);                                                                                             \
-        FS2T_MFMA(SET, 3, 0, av_); FS2T_MFMA(SET, 3, 1, av_); FS2T_MFMA(SET, 3, 2, av_); FS2T_MFMA(SET, 3, 3, av_); FS2T_FENCE(); \
-    } while (0)
-
-    // DMA schedule, identical for every wave and step position (so every vmcnt is a constant): the refill after the barrier of
-    // step (half, tap) issues the two weight pieces of the same tap of the NEXT half chunk into the slot just released, then
-    // T_NA(tap) pieces of a halo tile: buffer `half` is free from tap TAPS-1 on and takes half `half` of the next chunk - 3 pieces at
-    // tap TAPS-1 and 2 each at taps 0, 1, 2 of the other half.
-#define T_NA(T_) ((T_) == TAPS - 1 ? 3 : ((T_) <= 2 ? 2 : 0))
-    // vmcnt before the barrier that publishes step (half, tap NT): the weight pieces of that step went out TAPS steps earlier, first
-    // thing in that refill; behind them that refill's halo pieces and TAPS - 2 whole refills (2 weight pieces + their halo pieces):
-    // 2 (TAPS - 2) + 9 - T_NA(NT - 1).  At NT = 0 the step also needs its halo tile, whose last pieces went out at tap 2 of the
-    // half chunk before: TAPS - 4 whole refills without halo pieces behind them.
-#define T_VMCNT(NT) ((NT) == 0 ? 2 * (TAPS - 4) : 2 * (TAPS - 2) + 9 - T_NA((NT) - 1))
-    // K-step (H, T) of the current chunk
-#define T_STEP(H, T, MASKED)                                                                                                \
-    do {                                                                                                                    \
-        constexpr int NH_ = ((T) == TAPS - 1) ? ((H) ^ 1) : (H), NT_ = ((T) == TAPS - 1) ? 0 : (T) + 1;                     \
-        /* (opaque re-definitions: the addresses and mask bits below are loop-invariant per tap; hoisted out of the chunk loop they */ \
-        /* cost hundreds of spilled registers) */                                                                           \
-        asm volatile("" : "+v"(kpack), "+v"(vm0), "+v"(vm1), "+v"(vm2), "+v"(vm3), "+v"(blane0), "+v"(blane1));             \
-        const bool l0_ = (vm0 >> (T)) & 1u, l1_ = (vm1 >> (T)) & 1u, l2_ = (vm2 >> (T)) & 1u, l3_ = (vm3 >> (T)) & 1u;      \
-        /* k-slice 0 (fragments prefetched by the previous step); reads of k-slice 1 of this step */                        \
-        FS2T_SLICE(0, MASKED, l0_, l1_, l2_, l3_, T_A_ADDR(T, 1), T_A_OFF(H, T), T_B_ADDR(T, 1), T_B_OFFS(T));              \
-        if (!(ABL & 64)) FS2T_WAIT_LGKM(0);                                                                                 \
-        FS2T_FENCE();                          /* every read of this step's slot / halo rows has landed */                  \
-        t_wait_vm<T_VMCNT(NT_)>();             /* my pieces of the next step have landed */                                 \
-        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();   /* next step published; this step's slot (and, at tap TAPS-1, buffer H) released */ \
-        /* refill: the same tap of the NEXT half chunk into the slot just released */                                       \
-        if ((H) == 0) T_ISSUE_B(wcur + 64, offB, offB2, T); else T_ISSUE_B(wnxt, offBn, offBn2, T);                         \
-        /* halo tiles: half H of the next chunk goes into buffer H once this half is done; the rest during the other half */  \
-        if ((T) == TAPS - 1) { T_ISSUE_A(m0nxt, xnxt + (H) * 64, H, 0); T_ISSUE_A(m0nxt, xnxt + (H) * 64, H, 1); T_ISSUE_A(m0nxt, xnxt + (H) * 64, H, 2); } \
-        if ((T) <= 2) {                                                                                                     \
-            if ((H) == 0) { T_ISSUE_A(m0cur, xcur + 64, 1, 3 + 2 * (T)); T_ISSUE_A(m0cur, xcur + 64, 1, 4 + 2 * (T)); }     \
-            else { T_ISSUE_A(m0nxt, xnxt, 0, 3 + 2 * (T)); T_ISSUE_A(m0nxt, xnxt, 0, 4 + 2 * (T)); }                        \
+        u32x4 a00 = Af[0][0], a01 = Af[0][1], a10 = Af[1][0], a11 = Af[1][1];                                               \
+        if (MASKED) {                                                                                                       \
+            if (!((vm0 >> (T)) & 1u)) { a00 = u32x4{0u, 0u, 0u, 0u}; a10 = u32x4{0u, 0u, 0u, 0u}; }                         \
+            if (!((vm1 >> (T)) & 1u)) { a01 = u32x4{0u, 0u, 0u, 0u}; a11 = u32x4{0u, 0u, 0u, 0u}; }                         \
         }                                                                                                                   \
         FS2T_FENCE();                                                                                                       \
-        /* k-slice 1; reads of k-slice 0 of the next step */                                                                \
-        FS2T_SLICE(1, MASKED, l0_, l1_, l2_, l3_, T_A_ADDR(NT_, 0), T_A_OFF(NH_, NT_), T_B_ADDR(NT_, 0), T_B_OFFS(NT_));    \
+        FS2T_MFMA(0, 0, 0, a00); FS2T_MFMA(0, 0, 1, a00); FS2T_MFMA(0, 0, 2, a00); FS2T_MFMA(0, 0, 3, a00);                 \
+        FS2T_MFMA(0, 1, 0, a01); FS2T_MFMA(0, 1, 1, a01); FS2T_MFMA(0, 1, 2, a01); FS2T_MFMA(0, 1, 3, a01);                 \
+        FS2T_MFMA(1, 0, 0, a10); FS2T_MFMA(1, 0, 1, a10); FS2T_MFMA(1, 0, 2, a10); FS2T_MFMA(1, 0, 3, a10);                 \
+        FS2T_MFMA(1, 1, 0, a11); FS2T_MFMA(1, 1, 1, a11); FS2T_MFMA(1, 1, 2, a11); FS2T_MFMA(1, 1, 3, a11);                 \
+        FS2T_FENCE();                                                                                                       \
     } while (0)
-#define T_HALF(H, MASKED)                                                                                                   \
+    // LOAD of K-step (H, T) of the current chunk.  DMA first: the slot of the PREVIOUS step (everybody left it at the last barrier)
+    // gets the same tap of the half chunk after the one it held; at tap 0 / 1 the halo buffer the previous half chunk used gets
+    // the half chunk after this one (3 + 2 pieces).
+#define T_LOAD(H, T)                                                                                                        \
     do {                                                                                                                    \
-        T_STEP(H, 0, MASKED); T_STEP(H, 1, MASKED); T_STEP(H, 2, MASKED); T_STEP(H, 3, MASKED); T_STEP(H, 4, MASKED);       \
-        if constexpr (TAPS == 9) { T_STEP(H, 5, MASKED); T_STEP(H, 6, MASKED); T_STEP(H, 7, MASKED); T_STEP(H, 8, MASKED); } \
+        asm volatile("" : "+v"(kpack), "+v"(blane0), "+v"(blane1));      /* (opaque: no hoisting of 4 TAPS address sets) */ \
+        if ((T) >= 1) { if ((H) == 0) T_ISSUE_B(wcur + 64, offB, (T) - 1); else T_ISSUE_B(wnxt, offBn, (T) - 1); }          \
+        else { if ((H) == 0) T_ISSUE_B(wcur, offB, TAPS - 1); else T_ISSUE_B(wcur + 64, offB, TAPS - 1); }                  \
+        if ((T) == 0) {                                                                                                     \
+            if ((H) == 0) { T_ISSUE_A(m0cur, xcur + 64, 1, 0); T_ISSUE_A(m0cur, xcur + 64, 1, 1); T_ISSUE_A(m0cur, xcur + 64, 1, 2); } \
+            else { T_ISSUE_A(m0nxt, xnxt, 0, 0); T_ISSUE_A(m0nxt, xnxt, 0, 1); T_ISSUE_A(m0nxt, xnxt, 0, 2); }              \
+        }                                                                                                                   \
+        if ((T) == 1) {                                                                                                     \
+            if ((H) == 0) { T_ISSUE_A(m0cur, xcur + 64, 1, 3); T_ISSUE_A(m0cur, xcur + 64, 1, 4); }                         \
+            else { T_ISSUE_A(m0nxt, xnxt, 0, 3); T_ISSUE_A(m0nxt, xnxt, 0, 4); }                                            \
+        }                                                                                                                   \
+        const unsigned aa0_ = T_A_ADDR(T, 0), aa1_ = T_A_ADDR(T, 1), bb0_ = T_B_ADDR(T, 0), bb1_ = T_B_ADDR(T, 1);          \
+        FS2T_FENCE();                                                                                                       \
+        FS2T_DS_READ(Af[0][0], aa0_, T_A_OFF(H, T)); FS2T_DS_READ(Bf[0][0], bb0_, T_B_OFFS(T));                             \
+        FS2T_DS_READ(Bf[0][1], bb0_, T_B_OFFS(T) + 2048); FS2T_DS_READ(Bf[0][2], bb0_, T_B_OFFS(T) + 4096);                 \
+        FS2T_DS_READ(Bf[0][3], bb0_, T_B_OFFS(T) + 6144); FS2T_DS_READ(Af[0][1], aa0_, T_A_OFF(H, T) + 2048);               \
+        FS2T_DS_READ(Af[1][0], aa1_, T_A_OFF(H, T)); FS2T_DS_READ(Bf[1][0], bb1_, T_B_OFFS(T));                             \
+        FS2T_DS_READ(Bf[1][1], bb1_, T_B_OFFS(T) + 2048); FS2T_DS_READ(Bf[1][2], bb1_, T_B_OFFS(T) + 4096);                 \
+        FS2T_DS_READ(Bf[1][3], bb1_, T_B_OFFS(T) + 6144); FS2T_DS_READ(Af[1][1], aa1_, T_A_OFF(H, T) + 2048);               \
+        /* landed, AS OUTPUTS of the wait: every later use or copy of a fragment register is ordered behind it */             \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[1][0]), "+v"(Af[1][1]), "+v"(Bf[0][0]), \
+                     "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]), "+v"(Bf[1][0]), "+v"(Bf[1][1]), "+v"(Bf[1][2]), "+v"(Bf[1][3]) :: "memory"); \
     } while (0)
 
+    // vmcnt before the barrier that publishes step (half, tap NT) - both groups wait at the end of the phase before the first
+    // group's LOAD of that step: at most this many of the wave's operations may still be in flight.  Its weight piece went out
+    // TAPS - 1 LOADs ago, first thing in that LOAD; after it came that LOAD's halo pieces, then TAPS - 2 LOADs of one weight piece
+    // each, of which the ones at tap 0 / 1 add 3 / 2 halo pieces: TAPS - 2 + 5 - (halo pieces a LOAD at tap NT issues).  At
+    // NT = 0 the step also needs its halo tile, whose last two pieces went out TAPS - 2 LOADs ago: TAPS - 2.
+#define T_VMCNT(NT) ((NT) == 0 ? TAPS - 2 : ((NT) == 1 ? TAPS + 1 : TAPS + 3))
+#define T_BARRIER() __builtin_amdgcn_s_barrier()
+    // one K-step of the chunk, first group (waves 0-3): COMPUTE(i) | LOAD(i + 1); the last step's LOAD belongs to the next chunk
+#define T_STEP_A(H, T, MASKED)                                                                                              \
+    do {                                                                                                                    \
+        constexpr int NH_ = ((T) == TAPS - 1) ? ((H) ^ 1) : (H), NT_ = ((T) == TAPS - 1) ? 0 : (T) + 1;                     \
+        T_COMPUTE(T, MASKED);                                                                                               \
+        t_wait_vm<T_VMCNT(NT_)>();             /* my pieces of the next step have landed */                                 \
+        T_BARRIER();                                                                                                        \
+        if ((H) == 1 && (T) == TAPS - 1) { T_ROTATE(); }                                                                    \
+        T_LOAD(NH_, NT_);                                                                                                   \
+        T_BARRIER();                                                                                                        \
+    } while (0)
+    // second group (waves 4-7): LOAD(i) | COMPUTE(i)
+#define T_STEP_B(H, T, MASKED)                                                                                              \
+    do {                                                                                                                    \
+        constexpr int NT_ = ((T) == TAPS - 1) ? 0 : (T) + 1;                                                                \
+        T_LOAD(H, T);                                                                                                       \
+        t_wait_vm<T_VMCNT(NT_)>();                                                                                          \
+        T_BARRIER();                                                                                                        \
+        T_COMPUTE(T, MASKED);                                                                                               \
+        T_BARRIER();                                                                                                        \
+    } while (0)
+#define T_HALF(G, H, MASKED)                                                                                                \
+    do {                                                                                                                    \
+        T_STEP_##G(H, 0, MASKED); T_STEP_##G(H, 1, MASKED); T_STEP_##G(H, 2, MASKED); T_STEP_##G(H, 3, MASKED); T_STEP_##G(H, 4, MASKED); \
+        if constexpr (TAPS == 9) { T_STEP_##G(H, 5, MASKED); T_STEP_##G(H, 6, MASKED); T_STEP_##G(H, 7, MASKED); T_STEP_##G(H, 8, MASKED); } \
+    } while (0)
+    // the chunk being multiplied moves on; so does the one after it
+#define T_ROTATE() do { xcur = xnxt; wcur = wnxt; m0cur = m0nxt; offB = offBn; T_ADVANCE_NEXT(); } while (0)
+
+    const bool grpA = wave < 4;
     FS2T_WAIT_LGKM(0);                                       // kernel arguments: lgkmcnt is ours from here
-    t_wait_vm<0>();                                          // my pieces of the first chunk have landed
-    __builtin_amdgcn_s_barrier();                            // ... and everybody's
-    {
-        const unsigned aa = T_A_ADDR(0, 0), ba = T_B_ADDR(0, 0);
-        FS2T_DS_READ(Af[0][0], aa, 0); FS2T_DS_READ(Bf[0][0], ba, 0); FS2T_DS_READ(Bf[0][1], ba, 2048);
-        FS2T_DS_READ(Bf[0][2], ba, 4096); FS2T_DS_READ(Bf[0][3], ba, 6144); FS2T_DS_READ(Af[0][1], aa, 2048);
-        FS2T_DS_READ(Af[0][2], aa, 4096); FS2T_DS_READ(Af[0][3], aa, 6144);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[0][2]), "+v"(Af[0][3]), "+v"(Bf[0][0]), "+v"(Bf[0][1]),
-                     "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
-    }
+    t_wait_vm<0>();                                          // my pieces of the first half chunk have landed
+    T_BARRIER();                                             // ... and everybody's
+    if (grpA) { T_LOAD(0, 0); }                              // phase -1: the first group's fragments of step 0
+    T_BARRIER();
     bool first_chunk = true;
     for (int k = 0; k < ntiles; ++k) {
         int mt, nt, kc0_, nparts;
@@ -323,61 +320,54 @@ __global__ void __launch_bounds__(256) conv_gemm_t_kernel(ConvGemmArgs a, PSched
             }
             return msk;
         };
-        unsigned vm0 = row_mask(m0 + wave * 128 + fl), vm1 = row_mask(m0 + wave * 128 + 32 + fl);
-        unsigned vm2 = row_mask(m0 + wave * 128 + 64 + fl), vm3 = row_mask(m0 + wave * 128 + 96 + fl);
-        const bool need_mask = __builtin_amdgcn_ballot_w64(vm0 != full_ || vm1 != full_ || vm2 != full_ || vm3 != full_) != 0ull;   // wave-uniform
+        unsigned vm0 = row_mask(m0 + wave * 64 + fl), vm1 = row_mask(m0 + wave * 64 + 32 + fl);
+        const bool need_mask = __builtin_amdgcn_ballot_w64(vm0 != full_ || vm1 != full_) != 0ull;      // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // (one chunk loop per mask variant: with the variant chosen inside ONE loop the register allocator parked the accumulators in
-        // scratch around the loop header)
-#define T_CHUNKS(MASKED)                                                                                                    \
-        for (int c = 0; c < nkc_k; ++c) {                                                                                   \
-            if (!first_chunk) {                                  /* the chunk being multiplied moves on; so does the one after it */ \
-                xcur = xnxt; wcur = wnxt; m0cur = m0nxt; offB = offBn; offB2 = offBn2;                                      \
-                T_ADVANCE_NEXT();                                                                                           \
-            }                                                                                                               \
-            first_chunk = false;                                                                                            \
-            T_HALF(0, MASKED); T_HALF(1, MASKED);                                                                           \
+        // (one chunk loop per group and mask variant: with the variant chosen inside ONE loop the register allocator parked the
+        // accumulators in scratch around the loop header)
+        if (grpA) {
+            if (need_mask) { for (int c = 0; c < nkc_k; ++c) { T_HALF(A, 0, true); T_HALF(A, 1, true); } }
+            else { for (int c = 0; c < nkc_k; ++c) { T_HALF(A, 0, false); T_HALF(A, 1, false); } }
+        } else {
+#define T_CHUNKS_B(MASKED)                                                                                                  \
+            for (int c = 0; c < nkc_k; ++c) {                                                                               \
+                if (!first_chunk) { T_ROTATE(); }                                                                           \
+                first_chunk = false;                                                                                        \
+                T_HALF(B, 0, MASKED); T_HALF(B, 1, MASKED);                                                                 \
+            }
+            if (need_mask) { T_CHUNKS_B(true) } else { T_CHUNKS_B(false) }
+#undef T_CHUNKS_B
         }
-        if (need_mask) { T_CHUNKS(true) } else { T_CHUNKS(false) }
-#undef T_CHUNKS
-        // the six fragments prefetched for the next unit's first k-slice: land them before the compiler may copy their registers
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[0][2]), "+v"(Af[0][3]), "+v"(Bf[0][0]), "+v"(Bf[0][1]),
-                     "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
-        // the wave's 128 x 128 as two 64 x 128 halves for the shared register epilogues
-        f32x16 (&acc_lo)[2][4] = *reinterpret_cast<f32x16 (*)[2][4]>(&acc[0]);
-        f32x16 (&acc_hi)[2][4] = *reinterpret_cast<f32x16 (*)[2][4]>(&acc[2]);
-
+        // (the first group holds the next unit's first fragments across the epilogue: landed inside its LOAD)
         if (ABL & 16) {
             float s_ = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s_ += acc[i][j][0];
             if (s_ == 12345.678f) reinterpret_cast<bf16_t*>(a.Y)[0] = 0;
         } else if (nparts > 1) {
-            t_epilogue_part(sc.tws + (size_t)sc.b * (T_TM * 128), acc_lo, 2 * wave, fl, fh);
-            t_epilogue_part(sc.tws + (size_t)sc.b * (T_TM * 128), acc_hi, 2 * wave + 1, fl, fh);
+            t_epilogue_part(sc.tws + (size_t)sc.b * (T_TM * 128), acc, wave, fl, fh);
         } else {
-            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc_lo, m0, n0, 2 * wave, fl, fh, nullptr, bias_s, lane)));
-            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc_hi, m0, n0, 2 * wave + 1, fl, fh, nullptr, bias_s, lane)));
+            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wave, fl, fh, nullptr, bias_s, lane)));
         }
         // stores and DMA loads share vmcnt and may retire out of order with each other: no counted wait is safe until the stores
         // are gone (the pieces already in flight for the next unit land meanwhile)
         t_wait_vm<0>();
     }
 #undef T_HALF
-#undef T_STEP
+#undef T_STEP_A
+#undef T_STEP_B
+#undef T_COMPUTE
+#undef T_LOAD
+#undef T_ROTATE
 #undef T_VMCNT
-#undef FS2T_SLICE
-#undef T_ROWMASK
-#undef T_LGKM
-#undef T_NA
 #undef FS2T_MFMA
 #undef FS2T_DS_READ
 #undef T_ISSUE_A
@@ -499,12 +489,12 @@ template <int TAPS, int ABL>
 static void t_launch(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream) {
     static Fs2DevOnce once;
     once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_t_kernel<TAPS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, TCfg<TAPS>::LDS); });
-    conv_gemm_t_kernel<TAPS, ABL><<<(unsigned)sc.G, 256, TCfg<TAPS>::LDS, stream>>>(a, sc);
+    conv_gemm_t_kernel<TAPS, ABL><<<(unsigned)sc.G, 512, TCfg<TAPS>::LDS, stream>>>(a, sc);
 }
 static void t_launch_any(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream, int abl) {
 #ifdef FS2_DEV
 #define T_ABL_CASE(K) case K: if (a.taps == 9) t_launch<9, K>(a, sc, stream); else t_launch<5, K>(a, sc, stream); return;
-    switch (abl) { T_ABL_CASE(1) T_ABL_CASE(2) T_ABL_CASE(4) T_ABL_CASE(16) T_ABL_CASE(17) T_ABL_CASE(21) T_ABL_CASE(96) T_ABL_CASE(113) default: break; }
+    switch (abl) { T_ABL_CASE(1) T_ABL_CASE(2) T_ABL_CASE(3) T_ABL_CASE(4) T_ABL_CASE(5) T_ABL_CASE(16) T_ABL_CASE(17) T_ABL_CASE(21) default: break; }
 #undef T_ABL_CASE
 #endif
     (void)abl;
