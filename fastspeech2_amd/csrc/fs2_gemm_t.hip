@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(512) conv_gemm_t_kernel(ConvGemmArgs a, PSched
     // ------------------------------------------------------------------ DMA side (every wave: its own 1 KiB pieces)
     // a piece = 16 rows x 64 bytes; lane l writes LDS position (row l >> 2, 16-byte chunk l & 3), which must hold the SOURCE chunk
     // (l & 3) ^ key(row), key(row) = (row >> 2) & 3 = (l >> 4) & 3 for every piece (pieces start at multiples of 16 rows).
-    int prow = lane >> 2;
+    const int prow = lane >> 2;
     const unsigned pchunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     const unsigned ldx2 = (unsigned)(a.ldx * 2), ldw2 = (unsigned)(a.ldw * 2), cin2 = (unsigned)(a.Cin * 2);
     const unsigned adst = smem_u + (unsigned)(wave * 1024);              // + buffer * A_BYTES + i * 8192: piece i of this wave
@@ -162,7 +162,6 @@ __global__ void __launch_bounds__(512) conv_gemm_t_kernel(ConvGemmArgs a, PSched
     do {                                                                                                                    \
         if (!(ABL & 1)) {                                                                                                   \
             const int i_ = ((I) == 4 && wave != 0) ? 3 : (I);                                                               \
-            asm volatile("" : "+v"(prow));                  /* (opaque: five hoisted row offsets were spilled, and a scratch reload waits on vmcnt(0)) */ \
             const int g_ = min(max((M0_) - a.pad + (wave + 8 * i_) * 16 + prow, 0), a.M - 1);                               \
             t_glds((unsigned)g_ * ldx2 + pchunk, (XP), adst + (unsigned)((BUF) * T_A_BYTES + i_ * 8192));                   \
         }                                                                                                                   \
@@ -194,111 +193,95 @@ __global__ void __launch_bounds__(512) conv_gemm_t_kernel(ConvGemmArgs a, PSched
 #define T_A_OFF(H_, T_) ((H_) * T_A_BYTES + (T_) * 64)
 #define T_B_OFFS(T_) (((T_) >= 4 ? (T_) - 4 : (T_)) * T_B_BYTES)
 
-    u32x4 Af[2][2], Bf[2][4];                                // [k-slice][mb], [k-slice][nb]: all twelve fragments of one K-step
+    u32x4 Af[2][2], Bf[2][4];
     f32x16 acc[2][4];
 #define FS2T_DS_READ(dst, addr, OFF)                                                                                        \
     do {                                                                                                                    \
         if (!(ABL & 4)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));                  \
         else asm volatile("" : "=v"(dst));                                                                                  \
     } while (0)
-#define FS2T_MFMA(S_, MB, NB, AV)                                                                                           \
-    do { if (!(ABL & 2)) acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bf[S_][NB]),      \
+#define FS2T_MFMA(SET, MB, NB, AV)                                                                                          \
+    do { if (!(ABL & 2)) acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bf[SET][NB]),     \
                                                                            __builtin_bit_cast(bf16x8, AV), acc[MB][NB], 0, 0, 0); } while (0)
-    // PING-PONG (MI355X_MICROARCH.md "Two waves per SIMD"): the matrix pipe is per SIMD and fully paced - a wave cannot slip an
-    // MFMA into a gap shorter than 32 cycles, so two waves that both interleave reads with their MFMAs fragment each other's
-    // stream (the previous version of this loop: 1 408 cycles per step for 1 024 of MFMA work with every wait removed).  Here
-    // the two waves of a SIMD alternate roles phase by phase, one barrier per phase:
-    //   COMPUTE(step)  16 MFMAs back to back on the twelve fragments the wave loaded in its previous phase;
-    //   LOAD(step)     the wave's DMA pieces (the refill of the slot everybody has just left, halo pieces at taps 0 / 1), then the
-    //                  twelve fragment reads of `step`, landed (lgkmcnt(0)) before the barrier.
-    // Waves 0-3 run COMPUTE(i) | LOAD(i+1), waves 4-7 LOAD(i) | COMPUTE(i): in every phase one wave of each SIMD multiplies while
-    // the other loads.  Slot (half, tap) is read in the phase before the first group's COMPUTE and in the next one, and refilled -
-    // with the same tap of the NEXT half chunk - from the LOAD that follows.
-#define T_COMPUTE(T, MASKED)                                                                                                \
+    // one k-slice: 8 MFMAs on fragment set SET, the six reads of the next slice into set SET^1, one behind each of the first six
+    // MFMAs; read order A0 B0 B1 B2 B3 A1, counted lgkmcnt (see fs2_gemm_p.hip FS2P_SLICE)
+#define T_LGKM4() do { if (!(ABL & 32)) FS2T_WAIT_LGKM(4); } while (0)
+#define FS2T_SLICE(SET, MASKED, LIVE0, LIVE1, AADDR, AOFF, BADDR, BOFF)                                                     \
     do {                                                                                                                    \
-        u32x4 a00 = Af[0][0], a01 = Af[0][1], a10 = Af[1][0], a11 = Af[1][1];                                               \
-        if (MASKED) {                                                                                                       \
-            if (!((vm0 >> (T)) & 1u)) { a00 = u32x4{0u, 0u, 0u, 0u}; a10 = u32x4{0u, 0u, 0u, 0u}; }                         \
-            if (!((vm1 >> (T)) & 1u)) { a01 = u32x4{0u, 0u, 0u, 0u}; a11 = u32x4{0u, 0u, 0u, 0u}; }                         \
-        }                                                                                                                   \
-        FS2T_FENCE();                                                                                                       \
-        FS2T_MFMA(0, 0, 0, a00); FS2T_MFMA(0, 0, 1, a00); FS2T_MFMA(0, 0, 2, a00); FS2T_MFMA(0, 0, 3, a00);                 \
-        FS2T_MFMA(0, 1, 0, a01); FS2T_MFMA(0, 1, 1, a01); FS2T_MFMA(0, 1, 2, a01); FS2T_MFMA(0, 1, 3, a01);                 \
-        FS2T_MFMA(1, 0, 0, a10); FS2T_MFMA(1, 0, 1, a10); FS2T_MFMA(1, 0, 2, a10); FS2T_MFMA(1, 0, 3, a10);                 \
-        FS2T_MFMA(1, 1, 0, a11); FS2T_MFMA(1, 1, 1, a11); FS2T_MFMA(1, 1, 2, a11); FS2T_MFMA(1, 1, 3, a11);                 \
-        FS2T_FENCE();                                                                                                       \
+        u32x4 av0, av1;                                                                                                     \
+        const unsigned aa_ = (AADDR), ba_ = (BADDR);                                                                        \
+        T_LGKM4(); FS2T_FENCE();                                                                                            \
+        av0 = Af[SET][0];                                                                                                   \
+        if (MASKED && !(LIVE0)) av0 = u32x4{0u, 0u, 0u, 0u};                                                                \
+        FS2T_MFMA(SET, 0, 0, av0); FS2T_FENCE();                                                                            \
+        FS2T_DS_READ(Af[SET ^ 1][0], aa_, (AOFF)); FS2T_FENCE();                                                            \
+        T_LGKM4(); FS2T_FENCE();                                                                                            \
+        FS2T_MFMA(SET, 0, 1, av0); FS2T_FENCE();                                                                            \
+        FS2T_DS_READ(Bf[SET ^ 1][0], ba_, (BOFF)); FS2T_FENCE();                                                            \
+        T_LGKM4(); FS2T_FENCE();                                                                                            \
+        FS2T_MFMA(SET, 0, 2, av0); FS2T_FENCE();                                                                            \
+        FS2T_DS_READ(Bf[SET ^ 1][1], ba_, (BOFF) + 2048); FS2T_FENCE();                                                     \
+        T_LGKM4(); FS2T_FENCE();                                                                                            \
+        FS2T_MFMA(SET, 0, 3, av0); FS2T_FENCE();                                                                            \
+        FS2T_DS_READ(Bf[SET ^ 1][2], ba_, (BOFF) + 4096); FS2T_FENCE();                                                     \
+        T_LGKM4(); FS2T_FENCE();                                                                                            \
+        av1 = Af[SET][1];                                                                                                   \
+        if (MASKED && !(LIVE1)) av1 = u32x4{0u, 0u, 0u, 0u};                                                                \
+        FS2T_MFMA(SET, 1, 0, av1); FS2T_FENCE();                                                                            \
+        FS2T_DS_READ(Bf[SET ^ 1][3], ba_, (BOFF) + 6144); FS2T_FENCE();                                                     \
+        FS2T_MFMA(SET, 1, 1, av1); FS2T_FENCE();                                                                            \
+        FS2T_DS_READ(Af[SET ^ 1][1], aa_, (AOFF) + 2048); FS2T_FENCE();                                                     \
+        FS2T_MFMA(SET, 1, 2, av1); FS2T_FENCE();                                                                            \
+        FS2T_MFMA(SET, 1, 3, av1); FS2T_FENCE();                                                                            \
     } while (0)
-    // LOAD of K-step (H, T) of the current chunk.  DMA first: the slot of the PREVIOUS step (everybody left it at the last barrier)
-    // gets the same tap of the half chunk after the one it held; at tap 0 / 1 the halo buffer the previous half chunk used gets
-    // the half chunk after this one (3 + 2 pieces).
-#define T_LOAD(H, T)                                                                                                        \
+
+    // vmcnt before the barrier that publishes step (half, tap NT): at most this many of the wave's operations may still be in
+    // flight.  The weight piece of (half, NT) was issued TAPS steps earlier, first thing after that step's barrier; after it came the
+    // halo pieces of that refill, then TAPS - 2 refills of one weight piece each, of which the ones at tap TAPS-1 / tap 0 add 3 / 2
+    // halo pieces: TAPS - 2 + 5 - (halo pieces issued at tap NT - 1).  At NT = 0 the step also needs its halo tile, whose last two
+    // pieces went out TAPS - 1 steps earlier, behind that refill's weight piece: TAPS - 2.
+#define T_VMCNT(NT) ((NT) == 0 ? TAPS - 2 : ((NT) == 1 ? TAPS + 1 : TAPS + 3))
+    // K-step (H, T) of the current chunk
+#define T_STEP(H, T, MASKED)                                                                                                \
     do {                                                                                                                    \
-        asm volatile("" : "+v"(kpack), "+v"(blane0), "+v"(blane1));      /* (opaque: no hoisting of 4 TAPS address sets) */ \
-        if ((T) >= 1) { if ((H) == 0) T_ISSUE_B(wcur + 64, offB, (T) - 1); else T_ISSUE_B(wnxt, offBn, (T) - 1); }          \
-        else { if ((H) == 0) T_ISSUE_B(wcur, offB, TAPS - 1); else T_ISSUE_B(wcur + 64, offB, TAPS - 1); }                  \
+        constexpr int NH_ = ((T) == TAPS - 1) ? ((H) ^ 1) : (H), NT_ = ((T) == TAPS - 1) ? 0 : (T) + 1;                     \
+        /* (opaque re-definitions: the addresses and mask bits below are loop-invariant per tap, and hoisting 4 TAPS of them */ \
+        /* out of the chunk loop cost 239 spilled VGPRs; recomputing them is 3 VALU per slice) */                             \
+        asm volatile("" : "+v"(kpack), "+v"(vm0), "+v"(vm1), "+v"(blane0), "+v"(blane1));                                   \
+        const bool live0 = (vm0 >> (T)) & 1u, live1 = (vm1 >> (T)) & 1u;                                                    \
+        /* k-slice 0 (fragments prefetched by the previous step); reads of k-slice 1 of this step */                        \
+        FS2T_SLICE(0, MASKED, live0, live1, T_A_ADDR(T, 1), T_A_OFF(H, T), T_B_ADDR(T, 1), T_B_OFFS(T));                    \
+        if (!(ABL & 64)) FS2T_WAIT_LGKM(0);                                                                                 \
+        FS2T_FENCE();                          /* every read of this step's slot / halo rows has landed */                  \
+        t_wait_vm<T_VMCNT(NT_)>();             /* my pieces of the next step have landed */                                 \
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();   /* next step published; this step's slot (and, at tap TAPS-1, buffer H) released */ \
+        /* refill: the same tap of the NEXT half chunk into the slot just released */                                       \
+        if ((H) == 0) T_ISSUE_B(wcur + 64, offB, T); else T_ISSUE_B(wnxt, offBn, T);                                        \
+        /* halo tiles: half H of the next chunk goes into buffer H once this half is done (3 pieces now, 2 one step later) */ \
+        if ((T) == TAPS - 1) { T_ISSUE_A(m0nxt, xnxt + (H) * 64, H, 0); T_ISSUE_A(m0nxt, xnxt + (H) * 64, H, 1); T_ISSUE_A(m0nxt, xnxt + (H) * 64, H, 2); } \
         if ((T) == 0) {                                                                                                     \
-            if ((H) == 0) { T_ISSUE_A(m0cur, xcur + 64, 1, 0); T_ISSUE_A(m0cur, xcur + 64, 1, 1); T_ISSUE_A(m0cur, xcur + 64, 1, 2); } \
-            else { T_ISSUE_A(m0nxt, xnxt, 0, 0); T_ISSUE_A(m0nxt, xnxt, 0, 1); T_ISSUE_A(m0nxt, xnxt, 0, 2); }              \
-        }                                                                                                                   \
-        if ((T) == 1) {                                                                                                     \
             if ((H) == 0) { T_ISSUE_A(m0cur, xcur + 64, 1, 3); T_ISSUE_A(m0cur, xcur + 64, 1, 4); }                         \
             else { T_ISSUE_A(m0nxt, xnxt, 0, 3); T_ISSUE_A(m0nxt, xnxt, 0, 4); }                                            \
         }                                                                                                                   \
-        const unsigned aa0_ = T_A_ADDR(T, 0), aa1_ = T_A_ADDR(T, 1), bb0_ = T_B_ADDR(T, 0), bb1_ = T_B_ADDR(T, 1);          \
         FS2T_FENCE();                                                                                                       \
-        FS2T_DS_READ(Af[0][0], aa0_, T_A_OFF(H, T)); FS2T_DS_READ(Bf[0][0], bb0_, T_B_OFFS(T));                             \
-        FS2T_DS_READ(Bf[0][1], bb0_, T_B_OFFS(T) + 2048); FS2T_DS_READ(Bf[0][2], bb0_, T_B_OFFS(T) + 4096);                 \
-        FS2T_DS_READ(Bf[0][3], bb0_, T_B_OFFS(T) + 6144); FS2T_DS_READ(Af[0][1], aa0_, T_A_OFF(H, T) + 2048);               \
-        FS2T_DS_READ(Af[1][0], aa1_, T_A_OFF(H, T)); FS2T_DS_READ(Bf[1][0], bb1_, T_B_OFFS(T));                             \
-        FS2T_DS_READ(Bf[1][1], bb1_, T_B_OFFS(T) + 2048); FS2T_DS_READ(Bf[1][2], bb1_, T_B_OFFS(T) + 4096);                 \
-        FS2T_DS_READ(Bf[1][3], bb1_, T_B_OFFS(T) + 6144); FS2T_DS_READ(Af[1][1], aa1_, T_A_OFF(H, T) + 2048);               \
-        /* landed, AS OUTPUTS of the wait: every later use or copy of a fragment register is ordered behind it */             \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[1][0]), "+v"(Af[1][1]), "+v"(Bf[0][0]), \
-                     "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]), "+v"(Bf[1][0]), "+v"(Bf[1][1]), "+v"(Bf[1][2]), "+v"(Bf[1][3]) :: "memory"); \
+        /* k-slice 1; reads of k-slice 0 of the next step */                                                                \
+        FS2T_SLICE(1, MASKED, live0, live1, T_A_ADDR(NT_, 0), T_A_OFF(NH_, NT_), T_B_ADDR(NT_, 0), T_B_OFFS(NT_));          \
+    } while (0)
+#define T_HALF(H, MASKED)                                                                                                   \
+    do {                                                                                                                    \
+        T_STEP(H, 0, MASKED); T_STEP(H, 1, MASKED); T_STEP(H, 2, MASKED); T_STEP(H, 3, MASKED); T_STEP(H, 4, MASKED);       \
+        if constexpr (TAPS == 9) { T_STEP(H, 5, MASKED); T_STEP(H, 6, MASKED); T_STEP(H, 7, MASKED); T_STEP(H, 8, MASKED); } \
     } while (0)
 
-    // vmcnt before the barrier that publishes step (half, tap NT) - both groups wait at the end of the phase before the first
-    // group's LOAD of that step: at most this many of the wave's operations may still be in flight.  Its weight piece went out
-    // TAPS - 1 LOADs ago, first thing in that LOAD; after it came that LOAD's halo pieces, then TAPS - 2 LOADs of one weight piece
-    // each, of which the ones at tap 0 / 1 add 3 / 2 halo pieces: TAPS - 2 + 5 - (halo pieces a LOAD at tap NT issues).  At
-    // NT = 0 the step also needs its halo tile, whose last two pieces went out TAPS - 2 LOADs ago: TAPS - 2.
-#define T_VMCNT(NT) ((NT) == 0 ? TAPS - 2 : ((NT) == 1 ? TAPS + 1 : TAPS + 3))
-#define T_BARRIER() __builtin_amdgcn_s_barrier()
-    // one K-step of the chunk, first group (waves 0-3): COMPUTE(i) | LOAD(i + 1); the last step's LOAD belongs to the next chunk
-#define T_STEP_A(H, T, MASKED)                                                                                              \
-    do {                                                                                                                    \
-        constexpr int NH_ = ((T) == TAPS - 1) ? ((H) ^ 1) : (H), NT_ = ((T) == TAPS - 1) ? 0 : (T) + 1;                     \
-        T_COMPUTE(T, MASKED);                                                                                               \
-        t_wait_vm<T_VMCNT(NT_)>();             /* my pieces of the next step have landed */                                 \
-        T_BARRIER();                                                                                                        \
-        if ((H) == 1 && (T) == TAPS - 1) { T_ROTATE(); }                                                                    \
-        T_LOAD(NH_, NT_);                                                                                                   \
-        T_BARRIER();                                                                                                        \
-    } while (0)
-    // second group (waves 4-7): LOAD(i) | COMPUTE(i)
-#define T_STEP_B(H, T, MASKED)                                                                                              \
-    do {                                                                                                                    \
-        constexpr int NT_ = ((T) == TAPS - 1) ? 0 : (T) + 1;                                                                \
-        T_LOAD(H, T);                                                                                                       \
-        t_wait_vm<T_VMCNT(NT_)>();                                                                                          \
-        T_BARRIER();                                                                                                        \
-        T_COMPUTE(T, MASKED);                                                                                               \
-        T_BARRIER();                                                                                                        \
-    } while (0)
-#define T_HALF(G, H, MASKED)                                                                                                \
-    do {                                                                                                                    \
-        T_STEP_##G(H, 0, MASKED); T_STEP_##G(H, 1, MASKED); T_STEP_##G(H, 2, MASKED); T_STEP_##G(H, 3, MASKED); T_STEP_##G(H, 4, MASKED); \
-        if constexpr (TAPS == 9) { T_STEP_##G(H, 5, MASKED); T_STEP_##G(H, 6, MASKED); T_STEP_##G(H, 7, MASKED); T_STEP_##G(H, 8, MASKED); } \
-    } while (0)
-    // the chunk being multiplied moves on; so does the one after it
-#define T_ROTATE() do { xcur = xnxt; wcur = wnxt; m0cur = m0nxt; offB = offBn; T_ADVANCE_NEXT(); } while (0)
-
-    const bool grpA = wave < 4;
     FS2T_WAIT_LGKM(0);                                       // kernel arguments: lgkmcnt is ours from here
-    t_wait_vm<0>();                                          // my pieces of the first half chunk have landed
-    T_BARRIER();                                             // ... and everybody's
-    if (grpA) { T_LOAD(0, 0); }                              // phase -1: the first group's fragments of step 0
-    T_BARRIER();
+    t_wait_vm<0>();                                          // my pieces of the first chunk have landed
+    __builtin_amdgcn_s_barrier();                            // ... and everybody's
+    {
+        const unsigned aa = T_A_ADDR(0, 0), ba = T_B_ADDR(0, 0);
+        FS2T_DS_READ(Af[0][0], aa, 0); FS2T_DS_READ(Bf[0][0], ba, 0); FS2T_DS_READ(Bf[0][1], ba, 2048);
+        FS2T_DS_READ(Bf[0][2], ba, 4096); FS2T_DS_READ(Bf[0][3], ba, 6144); FS2T_DS_READ(Af[0][1], aa, 2048);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
+    }
     bool first_chunk = true;
     for (int k = 0; k < ntiles; ++k) {
         int mt, nt, kc0_, nparts;
@@ -329,22 +312,22 @@ __global__ void __launch_bounds__(512) conv_gemm_t_kernel(ConvGemmArgs a, PSched
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // (one chunk loop per group and mask variant: with the variant chosen inside ONE loop the register allocator parked the
-        // accumulators in scratch around the loop header)
-        if (grpA) {
-            if (need_mask) { for (int c = 0; c < nkc_k; ++c) { T_HALF(A, 0, true); T_HALF(A, 1, true); } }
-            else { for (int c = 0; c < nkc_k; ++c) { T_HALF(A, 0, false); T_HALF(A, 1, false); } }
-        } else {
-#define T_CHUNKS_B(MASKED)                                                                                                  \
-            for (int c = 0; c < nkc_k; ++c) {                                                                               \
-                if (!first_chunk) { T_ROTATE(); }                                                                           \
-                first_chunk = false;                                                                                        \
-                T_HALF(B, 0, MASKED); T_HALF(B, 1, MASKED);                                                                 \
-            }
-            if (need_mask) { T_CHUNKS_B(true) } else { T_CHUNKS_B(false) }
-#undef T_CHUNKS_B
+        // (one chunk loop per mask variant: with the variant chosen inside ONE loop the register allocator parked the accumulators in
+        // scratch around the loop header)
+#define T_CHUNKS(MASKED)                                                                                                    \
+        for (int c = 0; c < nkc_k; ++c) {                                                                                   \
+            if (!first_chunk) {                                  /* the chunk being multiplied moves on; so does the one after it */ \
+                xcur = xnxt; wcur = wnxt; m0cur = m0nxt; offB = offBn;                                                      \
+                T_ADVANCE_NEXT();                                                                                           \
+            }                                                                                                               \
+            first_chunk = false;                                                                                            \
+            T_HALF(0, MASKED); T_HALF(1, MASKED);                                                                           \
         }
-        // (the first group holds the next unit's first fragments across the epilogue: landed inside its LOAD)
+        if (need_mask) { T_CHUNKS(true) } else { T_CHUNKS(false) }
+#undef T_CHUNKS
+        // the six fragments prefetched for the next unit's first k-slice: land them before the compiler may copy their registers
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
+
         if (ABL & 16) {
             float s_ = 0.f;
 #pragma unroll
@@ -362,12 +345,9 @@ __global__ void __launch_bounds__(512) conv_gemm_t_kernel(ConvGemmArgs a, PSched
         t_wait_vm<0>();
     }
 #undef T_HALF
-#undef T_STEP_A
-#undef T_STEP_B
-#undef T_COMPUTE
-#undef T_LOAD
-#undef T_ROTATE
+#undef T_STEP
 #undef T_VMCNT
+#undef FS2T_SLICE
 #undef FS2T_MFMA
 #undef FS2T_DS_READ
 #undef T_ISSUE_A
@@ -494,7 +474,7 @@ static void t_launch(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream
 static void t_launch_any(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream, int abl) {
 #ifdef FS2_DEV
 #define T_ABL_CASE(K) case K: if (a.taps == 9) t_launch<9, K>(a, sc, stream); else t_launch<5, K>(a, sc, stream); return;
-    switch (abl) { T_ABL_CASE(1) T_ABL_CASE(2) T_ABL_CASE(3) T_ABL_CASE(4) T_ABL_CASE(5) T_ABL_CASE(16) T_ABL_CASE(17) T_ABL_CASE(21) default: break; }
+    switch (abl) { T_ABL_CASE(1) T_ABL_CASE(2) T_ABL_CASE(3) T_ABL_CASE(16) T_ABL_CASE(17) T_ABL_CASE(32) T_ABL_CASE(96) T_ABL_CASE(33) T_ABL_CASE(97) T_ABL_CASE(113) default: break; }
 #undef T_ABL_CASE
 #endif
     (void)abl;
