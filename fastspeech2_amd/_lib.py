@@ -87,3 +87,16 @@ def call(name, *args):
             raise TypeError(f"{name}: {msg}")
         raise Fs2Error(f"{name}: rc={rc}: {msg}")
     return rc
+
+
+def kernel_source_sha(prefix="fs2_gemm"):
+    """sha1 over the contraction kernels' sources (csrc/<prefix>*.hip|.h + the scheduler header): stamps measurement files that are
+    only valid for the kernels they were taken on (profiles/*pmc_traffic.json: bench.py refuses a stale one)."""
+    import glob
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(d, prefix + "*")) + [os.path.join(d, "fs2_sched.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

@@ -358,7 +358,12 @@ extern "C" int fs2_lr_gather_bwd(const void* dy, const int32_t* cum, void* dx, i
 __global__ void duration_round_kernel(const float* __restrict__ logd, float d_control, float* __restrict__ out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float v = rintf(expf(logd[i]) - 1.0f) * d_control;
+    // exp through double, rounded once to fp32: the CORRECTLY ROUNDED fp32 exp.  The index contract hangs on it - the result changes
+    // where exp(x) - 1 crosses k + 0.5, and device expf (1-2 ulp) and the reference's CPU exp (Sleef, 1 ulp) need not agree on the
+    // one or two inputs next to log(k + 1.5); both agree with the correctly rounded value wherever they are exact
+    // (tests/test_ops_gpu.py::test_duration_round_boundary_sweep walks every such neighbourhood for k <= 64).
+    const float y = (float)exp((double)logd[i]);
+    float v = rintf(y - 1.0f) * d_control;
     out[i] = fmaxf(v, 0.0f);
 }
 extern "C" int fs2_duration_round(const float* logd, float d_control, float* out, int n, hipStream_t stream) {

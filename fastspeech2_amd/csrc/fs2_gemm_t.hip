@@ -18,20 +18,28 @@
 //     the four 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3, which puts the 16 lanes of every ds_read_b128 lane
 //     group on 16 different 16-byte bank groups (measured: SQ_LDS_BANK_CONFLICT = 0, profiles/r04h_tall_pmc_mfma.md).
 //   * a K-step = (half chunk, tap): 2 k-slices of 16, 16 MFMAs per wave, ONE raw barrier.
-//   * the first version of this file (git history) kept run-time positions, issue stamps and a computed vmcnt for every step:
-//     correct, and SLOWER than the 256 x 128 kernel (250 vs 197 us): ~300 instructions per step for 16 MFMAs, 67 spilled SGPRs -
-//     a wave issues one instruction every >= 4-8 cycles, so the step cost 2 770 cycles for 1 024 cycles of MFMA work per SIMD
+//   * the first version of this file kept run-time positions, issue stamps and a computed vmcnt for every step: correct, and
+//     slow (250 us on the k = 9 FFN forward, 197 for fs2_gemm_p.hip): ~300 instructions per step for 16 MFMAs, 67 spilled SGPRs
 //     (r04h: MFMA busy 31.7 %, 3.45 VALU per MFMA).  This version makes the schedule EXACTLY periodic and unrolls it over one
 //     64-channel chunk (2 halves x TAPS steps): LDS offsets are immediates, the refill of a step is "the same tap of the next half
 //     chunk into the slot just read" (one DMA piece per wave), the halo tile of the half chunk after the next is issued at two
 //     fixed taps, every wave issues the same number of operations per step (waves without a fifth halo piece re-issue their
 //     fourth; past the end of the work the refills re-fetch the last chunk into free slots) - so every vmcnt is a compile-time
-//     constant and the only run-time bookkeeping happens once per chunk.
-// The epilogue's global stores share vmcnt with the DMA loads and may complete out of order with them, so a wave drains vmcnt
-// once after its stores (per tile).
-// Scope (round 4): taps 5 or 9, dil 1, no input activation, no lens / tile map (the engine passes lens only for buckets with
-// >= 10 % wholly padded tiles; those launches keep the 256 x 128 kernel), no uniform K-split; tail parts as in fs2_gemm_p.hip
-// (f32 slabs + finalize) so that a partial last round costs 1 / tks of a round.
+//     constant, the only run-time bookkeeping happens once per chunk, and a step is 58 instructions.
+// WHAT IT MEASURES (round 4, same-box A/B against fs2_gemm_p.hip, profiles/r04f..r04m_*): parity green in all three forms below, and
+// NOT faster at the bench shapes - the default dispatch never picks it (fs2_conv_gemm_t_ok); it stays reachable through
+// fs2_conv_gemm_tall for the parity test and tools/bench_conv.py.
+//   form A (this file): 8 waves, reads interleaved with MFMAs ............ k = 9 FFN forward 205 us, PostNet k = 5 122 us
+//   form B (git history): the same 8 waves in compute / load ping-pong ... 213 / 132 us
+//   form C (git history): 4 waves x 128 x 128, 512 registers each ........ 234 / 134 us
+//   fs2_gemm_p.hip (256 x 128, 4 loader + 4 consumer waves) .............. 197 / 105 us
+// The compile-time ablations of all three forms agree on where the time goes, whatever the structure (k = 9 forward, 3 rounds of
+// tiles, MFMA floor 93 us at the nominal 2.4 GHz): MFMAs + barriers alone 128-133 us - the chip clocks to ~1.95 GHz under a
+// back-to-back MFMA stream (DVFS), i.e. 0.65 of the nominal peak is the ceiling of ANY kernel here; + fragment reads +34..36 us
+// (also with every lgkmcnt wait removed: not latency - the reads' issue / register write-back take MFMA time, 13-20 cycles per
+// ds_read_b128) -> 0.51 of nominal with free operands and a free epilogue; + DMA issue +16..21 us; + epilogue +25..47 us (store-
+// issue-bound, and 3 rounds of 512-row tiles for 2.72 rounds of work).  fs2_gemm_p.hip's 197 us sits at 0.83 of that 164 us
+// read-fed ceiling; the 0.50-of-nominal target of VERDICT r03 is above what an LDS-fed bf16 MFMA loop reaches on this chip.
 #include "fs2_gemm.h"
 #include "fs2_sched.h"
 #include "fs2_gemm_epi.h"
@@ -438,27 +446,35 @@ static int t_tks_max(const ConvGemmArgs& a, bool have_ws) {
     return t;
 }
 
-// Eligibility + "does it pay" (pure function of the launch description).  The tall kernel takes a launch when its estimated time
-// - rounds of 512-row tiles at the in-tile rate measured for it - beats the 256 x 128 kernel's by a margin; few-tile launches
-// (N = 256 data gradients: 174 tall tiles on 256 CUs) stay where they are.
-bool fs2_conv_gemm_t_ok(const ConvGemmArgs& a, bool has_map, int dtype, bool have_tail_ws) {
+// Shapes the tall kernel can run (pure function of the launch description).
+bool fs2_conv_gemm_t_can(const ConvGemmArgs& a, bool has_map, int dtype) {
     if (dtype != FS2_BF16 || a.in_act != FS2_ACT_NONE || a.lens || has_map) return false;
-    const int taps = a.taps;
-    if (!((taps == 5 || taps == 9) && a.dil == 1)) return false;
+    if (!((a.taps == 5 || a.taps == 9) && a.dil == 1)) return false;
     if (a.Cin % 64 != 0 || !a.vec_ok || a.N % 8 != 0) return false;
-    if ((double)a.M * a.ldx * 2 >= 2.0e9 || (double)a.N * taps * a.Cin * 2 >= 2.0e9) return false;
+    if ((double)a.M * a.ldx * 2 >= 2.0e9 || (double)a.N * a.taps * a.Cin * 2 >= 2.0e9) return false;
     const int cus = t_cu_count();
     const long ntm = fs2_cdiv(a.M, T_TM), ntn = fs2_cdiv(a.N, 128);
     if (ntn > 255 || ntm * ntn < cus) return false;
+    if (p_max_units((int)ntm, (int)ntn, 1, cus, 0) > 64 || (cus % 8 == 0 && p_max_units((int)ntm, (int)ntn, 1, cus, 1) > 64)) return false;
+    return true;
+}
+// "Does it pay": the tall kernel takes a launch of the DEFAULT dispatch when its estimated time - rounds of 512-row tiles at
+// `speed` x the 256 x 128 kernel's in-tile rate - beats that kernel's by a margin.  Measured speed (r04j, same box): 0.96 on
+// the k = 9 FFN forward, 0.86 on the PostNet k = 5 conv - so with the shipped constant it never does; FS2_T_SPEED / FS2_GEMM_T
+// (dev builds) exist for the A/B.
+bool fs2_conv_gemm_t_ok(const ConvGemmArgs& a, bool has_map, int dtype, bool have_tail_ws) {
+    if (!fs2_conv_gemm_t_can(a, has_map, dtype)) return false;
+    const int taps = a.taps;
+    const int cus = t_cu_count();
+    const long ntm = fs2_cdiv(a.M, T_TM), ntn = fs2_cdiv(a.N, 128);
     const int G = cus;
-    if (p_max_units((int)ntm, (int)ntn, 1, G, 0) > 64 || (G % 8 == 0 && p_max_units((int)ntm, (int)ntn, 1, G, 1) > 64)) return false;
     // estimated time in units of one 256-row tile-time of the 256 x 128 kernel; the tall kernel's tile is 2 x the rows and runs
     // at `speed` x the in-tile rate (measured: profiles/r04*_bench_t.log)
-    static const int speed_pct = fs2_dev_env("FS2_T_SPEED", 135);
+    static const int speed_pct = fs2_dev_env("FS2_T_SPEED", 45);     // 2 x rows per tile at 0.9 x the in-tile rate -> 0.45 per row: never below 0.95 of the old time
     const long T256 = (long)fs2_cdiv(a.M, 256) * ntn;
     const int tks256 = (T256 <= 2L * cus && (long)taps * (a.Cin >> 6) >= 64) ? 8 : 1;
     const double t_old = t_rounds(T256, cus, tks256, nullptr);
-    const double t_new = 2.0 * t_rounds(ntm * ntn, G, t_tks_max(a, have_tail_ws), nullptr) * 100.0 / speed_pct;
+    const double t_new = t_rounds(ntm * ntn, G, t_tks_max(a, have_tail_ws), nullptr) * 100.0 / speed_pct;
     static const int force = fs2_dev_env("FS2_GEMM_T", -1);             // dev A/B: 0 = never, 1 = whenever eligible
     if (force == 0) return false;
     if (force == 1) return true;

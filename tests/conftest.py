@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """every skipped test WITH its reason, whatever the verbosity (the driver runs `-x -q`, which hides them: a self-skipping
+    RCCL test must say that it skipped because the box has one GPU - VERDICT r03 next 7)"""
+    skipped = terminalreporter.stats.get("skipped", [])
+    for rep in skipped:
+        reason = rep.longrepr[2] if isinstance(rep.longrepr, tuple) and len(rep.longrepr) == 3 else str(rep.longrepr)
+        terminalreporter.write_line(f"SKIPPED {rep.nodeid}: {reason}")
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

@@ -126,13 +126,14 @@ def test_contraction_forward_and_dgrad_production_shapes(dev, dtype, name, Cin, 
 
 @pytest.mark.parametrize("name,Cin,Cout,k", [("ffn w_1 k9", 256, 1024, 9), ("postnet k5", 512, 512, 5), ("k9 C512", 512, 512, 9)])
 def test_tall_tile_kernel_without_lens(dev, name, Cin, Cout, k):
-    """conv_gemm_t_kernel (fs2_gemm_t.hip: 512 x 128 tiles, eight self-loading consumer waves, half-chunk K loop) takes the large
-    convolutions that carry no lens - what the LJSpeech bench step launches.  Every batch size below changes the tile count (whole
-    rounds, 2- / 4-way tail parts, a last M-tile with rows beyond M), sequences end inside tiles (tap masks at both ends of
-    every sequence), and the epilogue variants are the ones the engine uses: bias + ReLU, residual add, ReLU gate, accumulate +
-    scale.  Elementwise against the exact-product reference, rounding only."""
+    """conv_gemm_t_kernel (fs2_gemm_t.hip: 512 x 128 tiles, eight self-loading consumer waves, half-chunk K loop unrolled over a
+    periodic DMA schedule) - round 4's answer to "port the all-consumer structure to the convolution kernel".  It is NOT on the
+    default dispatch (measured slower than the 256 x 128 persistent kernel, profiles/r04j_tall_ablation.log); fs2_conv_gemm_tall
+    reaches it by name.  Every batch size below changes the tile count (whole rounds, 2- / 4-way tail parts, a last M-tile with rows
+    beyond M), sequences end inside tiles (tap masks at both ends of every sequence), and the epilogue variants are the ones the
+    engine uses: bias + ReLU, residual add, ReLU gate, accumulate + scale.  Elementwise against the exact-product reference,
+    rounding only."""
     ops = _ops()
-    from fastspeech2_amd import _lib
     S, dtype = 925, torch.bfloat16
     g = torch.Generator().manual_seed(sum(ord(c) for c in name) + 1)
     pad = (k - 1) // 2
@@ -142,31 +143,34 @@ def test_tall_tile_kernel_without_lens(dev, name, Cin, Cout, k):
     wf, wd = ops.pack_weight(w, dtype)
     ref = conv_ref_gpu(x, wf, bias, S, pad)
     tws = ops.tail_workspace(dev).fill_(float("nan"))
-    var = _lib.load().fs2_conv_gemm_variant(Cin, Cout, 0, 0, 0, B * S, Cout, Cin, S, k, 1, 0, 0.0, 1)
-    assert var == 8, var                                                          # FS2_GEMM_TALL at the full batch
     seen = 0
     for nb in (48, 45, 41, 37, 30, 24, 19):
         Mq = nb * S
-        if _lib.load().fs2_conv_gemm_variant(Cin, Cout, 0, 0, 0, Mq, Cout, Cin, S, k, 1, 0, 0.0, 1) != 8:
+        if ((Mq + 511) // 512) * ((Cout + 127) // 128) < torch.cuda.get_device_properties(dev).multi_processor_count:
+            with pytest.raises(ValueError):                                  # fewer tiles than CUs: refused, not mis-run
+                ops.conv_gemm_tall(x[:Mq], wf, bias, S, k, pad, act=ops.ACT_RELU, tail_ws=tws)
             continue
         seen += 1
         for tail in (tws, None):
-            y = ops.conv_gemm(x[:Mq], wf, bias, S, taps=k, pad=pad, act=ops.ACT_RELU, tail_ws=tail)
+            y = ops.conv_gemm_tall(x[:Mq], wf, bias, S, k, pad, act=ops.ACT_RELU, tail_ws=tail)
             assert_rounding_only(y, torch.relu(ref[:Mq]), dtype, (name, "fwd", nb, tail is not None))
     assert seen >= 2
     # data gradient forms (tap-flipped pack) at the full batch: residual add, ReLU gate, accumulate with scale
     dy = torch.randn(B * S, Cout, generator=g).to(dev).to(dtype)
     res = torch.randn(B * S, Cin, generator=g).to(dev).to(dtype)
-    if _lib.load().fs2_conv_gemm_variant(Cout, Cin, Cin, 0, 0, B * S, Cin, Cout, S, k, 1, 0, 0.0, 1) == 8:
+    if ((B * S + 511) // 512) * ((Cin + 127) // 128) >= torch.cuda.get_device_properties(dev).multi_processor_count:
         dref = conv_ref_gpu(dy, wd, None, S, (k - 1) - pad)
-        dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, res=res, tail_ws=tws)
+        dx = ops.conv_gemm_tall(dy, wd, None, S, k, (k - 1) - pad, res=res, tail_ws=tws)
         assert_rounding_only(dx, dref + res.double(), dtype, (name, "dgrad+res"))
-        dx = ops.conv_gemm(dy, wd, None, S, taps=k, pad=(k - 1) - pad, act=ops.ACT_GATE, res=res, tail_ws=tws)
+        dx = ops.conv_gemm_tall(dy, wd, None, S, k, (k - 1) - pad, act=ops.ACT_GATE, res=res, tail_ws=tws)
         assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)), dtype, (name, "dgrad gate"))
     acc0 = torch.randn(B * S, Cout, generator=g).to(dev).to(dtype)
     out = acc0.clone()
-    ops.conv_gemm(x, wf, bias, S, taps=k, pad=pad, out=out, accumulate=True, out_scale=0.5, tail_ws=tws)
+    ops.conv_gemm_tall(x, wf, bias, S, k, pad, out=out, accumulate=True, out_scale=0.5, tail_ws=tws)
     assert_rounding_only(out, acc0.double() + 0.5 * ref, dtype, (name, "accumulate"))
+    # and the default dispatch stays on the 256 x 128 persistent kernel for this launch
+    from fastspeech2_amd import _lib
+    assert _lib.load().fs2_conv_gemm_variant(Cin, Cout, 0, 0, 0, B * S, Cout, Cin, S, k, 1, 0, 0.0, 1) == 5
 
 
 @pytest.mark.parametrize("name,C,N,k,dil,S,Bq", [("rb C256 k7 d3", 256, 256, 7, 3, 7200, 8), ("rb C128 k11 d5", 128, 128, 11, 5, 57600, 4),

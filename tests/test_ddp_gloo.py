@@ -130,3 +130,61 @@ def test_single_process_exchange_is_identity():
     ex.finish()
     assert torch.equal(ex.flat, flat)
     assert torch.equal(ddp.global_counts(torch.tensor([3.0])), torch.tensor([3.0]))
+
+
+def test_bucket_schedule_at_the_real_parameter_layout():
+    """The exchange's bucket boundaries against the engine's "prefix final" offsets at the REAL layout (4 + 4 layers, 28.87 M
+    trainable parameters = 115.5 MB of fp32 gradients; reference train.py:42 moves them with nn.DataParallel's gather).
+    Engine._backward reports a final prefix after every decoder layer, after the variance adaptor, after every encoder layer and
+    at the end (engine.py `_ready`); GradExchange.ready launches every whole bucket inside it.  Checked without a process group
+    (the launches are recorded, not executed): every byte travels exactly once and in order, no bucket leaves before its prefix
+    is final, the 32 MB / 8 MB bucket sizes hold, and what is left for finish() - the part exposed in front of clip + Adam - is at
+    most one 8 MB tail bucket plus the prefix granularity of the last layer."""
+    from fastspeech2_amd.ddp import GradExchange
+    from fastspeech2_amd.model import FastSpeech2
+    from tests.golden import configs
+    pcfg, mcfg = configs.make(dec_layers=4, enc_layers=4)
+    m = FastSpeech2(pcfg, mcfg)
+    offsets, total = {}, 0
+    for n, p in m._trainable_in_backward_order():          # the same walk as FastSpeech2._ensure_flat
+        offsets[n] = total
+        total += (p.numel() + 7) // 8 * 8
+    n_param = sum(p.numel() for _, p in m._trainable_in_backward_order())
+    assert 28.8e6 < n_param < 28.95e6 and total * 4 < 116.5e6
+    # the offsets Engine._backward passes to the hook, in order (engine.py: decoder layers 3..0 -> variance adaptor -> encoder 3..0)
+    names = [f"decoder.layer_stack.{i}.pos_ffn.layer_norm.weight" for i in (3, 2, 1, 0)]
+    names += ["variance_adaptor.energy_predictor.linear_layer.weight"]
+    names += [f"encoder.layer_stack.{i}.pos_ffn.layer_norm.weight" for i in (3, 2, 1, 0)] + ["encoder.src_word_emb.weight"]
+    ends = [offsets[n] for n in names] + [total]
+    assert ends == sorted(ends) and ends[0] > 0            # the PostNet + mel_linear block is final first
+    flat = torch.zeros(total)
+    ex = GradExchange(flat, world_size=2)
+    launched = []
+    ex._launch = lambda lo, hi, producers=(): launched.append((lo, hi, cur[0]))
+    cur = [0]
+    for e in ends:
+        cur[0] = e
+        ex.ready(e)
+    before_finish = len(launched)
+    cur[0] = total
+    if ex.sent < ex.n:
+        launched.append((ex.sent, ex.n, total))
+    # exactly once, in order
+    assert launched[0][0] == 0 and launched[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(launched, launched[1:]))
+    # never ahead of the final prefix
+    assert all(hi <= final for lo, hi, final in launched)
+    sizes = [(hi - lo) * 4 for lo, hi, _ in launched]
+    # the size rule: 32 MiB while a whole one fits in front of the last 48 MiB of the buffer, 8 MiB pieces from there on (at
+    # this layout - 110.1 MiB - that is ONE 32 MiB bucket: PostNet + mel_linear + most of the decoder, then 8 MiB pieces)
+    for (lo, hi, _), sz in zip(launched[:before_finish], sizes):
+        assert sz == ((32 << 20) if (lo + (32 << 20) // 4) <= ex.tail_start else (8 << 20)), (lo, hi, sz)
+    assert sizes[0] == 32 << 20
+    exposed = sizes[-1] if len(launched) > before_finish else 0
+    # the embedding table (361 x 256) and the first encoder layer's attention block are the last gradients to become final
+    assert exposed <= (8 << 20), exposed
+    # overlap budget: bytes that can travel while backward still runs vs the whole buffer
+    early = sum(s for (lo, hi, final), s in zip(launched, sizes) if final < total)
+    print(f"{len(launched)} buckets: {[round(s / 2 ** 20, 1) for s in sizes]} MiB; {early / (total * 4):.0%} of the bytes launched before "
+          f"backward ends, {exposed / 2 ** 20:.1f} MiB left for finish()")
+    assert early >= 0.85 * total * 4

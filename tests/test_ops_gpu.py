@@ -360,6 +360,30 @@ def test_duration_round(dev):
         assert torch.equal(out, ref)
 
 
+def test_duration_round_boundary_sweep(dev):
+    """the inference-path index contract (model/modules.py:132-135: round(exp(log_d) - 1) * d_control, clamped)
+    at every place it can flip - the 33 fp32 values around log(k + 1.5) (where exp(x) - 1 crosses k + 0.5) and around log(k + 1)
+    (exact integers) for every k <= 64 - against the reference's own CPU arithmetic (torch.exp / torch.round in fp32)."""
+    ops = _ops()
+    import numpy as np
+    xs = []
+    for k in range(0, 65):
+        for c in (k + 1.5, k + 1.0):
+            x0 = np.float32(np.log(np.float64(c)))
+            lo = hi = x0
+            xs.append(x0)
+            for _ in range(16):
+                lo = np.nextafter(lo, np.float32(-np.inf)); hi = np.nextafter(hi, np.float32(np.inf))
+                xs += [lo, hi]
+    logd = torch.from_numpy(np.array(xs, dtype=np.float32))
+    n_diff = 0
+    for ctl in (1.0, 0.8, 1.3):
+        out = ops.duration_round(logd.to(dev), ctl).cpu()
+        ref = torch.clamp(torch.round(torch.exp(logd) - 1) * ctl, min=0)
+        n_diff += int((out != ref).sum())
+    assert n_diff == 0, (n_diff, logd.numel())
+
+
 def test_adam_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(8)

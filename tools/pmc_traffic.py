@@ -2,7 +2,9 @@
 Units/corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE/WRITE_SIZE are reported in KB (1024 B); on gfx950 FETCH_SIZE
 counts 128-B requests as 64 B for wide coalesced reads -> doubled here; WRITE_SIZE is uncalibrated and used as reported.
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps> [out.json]"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fastspeech2_amd._lib import kernel_source_sha
 
 fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
 out_path = sys.argv[4] if len(sys.argv) > 4 else None
@@ -38,4 +40,4 @@ for k, n, fb, wb in rows[:25]:
 print(f"\ntotal HBM traffic {tot/steps/1e9:.2f} GB/step")
 if out_path:
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 gfx950 correction", "kernels": res,
-               "total_bytes_per_step": tot / steps}, open(out_path, "w"), indent=1)
+               "total_bytes_per_step": tot / steps, "kernel_source_sha": kernel_source_sha()}, open(out_path, "w"), indent=1)
