@@ -554,8 +554,6 @@ struct BnArgs {
     const float* mean_rstd; const float* gamma; const float* beta;
     float* sums;                 // stats / bwd sums (2C floats): WRITTEN by the last row group of each channel block (reducing modes)
     float* slab;                 // reducing modes: [row group][pass][C] partial sums (plain stores; summed in index order)
-    unsigned* counter;           // reducing modes: one arrival counter per channel block; zero between launches
-    float* acc_dbeta; float* acc_dgamma;   // MODE 3 (optional): parameter gradients += sums (workgroup 0)
     int M, C, cprp, rows_per_block, act;
     int cblk;                    // channels per workgroup (grid.y walks the channel blocks); cprp * V when one workgroup spans the row
     float p; uint64_t seed; const uint64_t* seed_dev;
@@ -575,9 +573,12 @@ __device__ __forceinline__ float fs2_tanh(float x) {
 // MODE 0: statistics   1: apply   2: backward pass 1 (sums)   3: backward pass 2 (dx)
 // Reducing modes (0, 2) run FEW fat workgroups (NT = 1024 threads, 4 rows in flight per thread).  Streaming modes (1, 3) use
 // many 256-thread workgroups.
-// The column sums are BIT-REPRODUCIBLE (r04): a workgroup stores its partial sums into its own row of a slab, and the LAST
-// workgroup to arrive at a channel block (device-scope counter) adds the partials in row-group order.  Rounds 1-3 used one
-// float atomic per channel and workgroup: the arrival order changed the last bits of mean / rstd / the backward sums from run to
+// The column sums are BIT-REPRODUCIBLE (r04): a workgroup stores its partial sums into its own row of a slab and a tiny second
+// launch (bn_slab_sum_kernel; for the forward statistics the finalize kernel that existed anyway) adds the rows in index order.
+// (First attempt: the last workgroup to arrive - device-scope counter + __threadfence - summed them in the same launch.  Correct,
+// and 4-6 x slower: on gfx950 an agent-scope fence is buffer_wbl2 + buffer_inv, i.e. every workgroup wrote back / invalidated
+// its XCD's L2 right behind a convolution that had left 45 MB of dirty lines there - statistics 14 -> 82 us, backward sums
+// 35 -> 127 us, profiles/r04p_kernel_trace_side0.md.)  Rounds 1-3 used one float atomic per channel and workgroup: the arrival order changed the last bits of mean / rstd / the backward sums from run to
 // run, bf16 rounding turned some of those into one-spacing differences in the PostNet's tensors, and the whole-step gradient
 // moved between runs of the same binary (profiles/r04a_spread_seed0.log: 6 runs, 6 different flat-gradient hashes, the
 // mel_linear.weight error 0.77 x .. 2.47 x the emulated one; r04b_spread_local.log: the first tensors that differ are the ones
@@ -619,12 +620,6 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
                 if (MODE == 3) { m1[k] = a.sums[c + k] / (float)a.M; m2[k] = a.sums[a.C + c + k] / (float)a.M; }
             }
         }
-    }
-    if (MODE == 3 && blockIdx.x == 0 && rl == 0 && cok && a.acc_dbeta) {
-        // the reduced sums ARE the affine gradients (sum g = dbeta, sum g*xhat = dgamma): workgroup 0 adds them into the
-        // parameter-gradient buffers
-#pragma unroll
-        for (int k = 0; k < V; ++k) { a.acc_dbeta[c + k] += a.sums[c + k]; a.acc_dgamma[c + k] += a.sums[a.C + c + k]; }
     }
     float a1[V], a2[V];
 #pragma unroll
@@ -684,7 +679,6 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
         }
     }
     if (MODE == 0 || MODE == 2) {                      // tree over the block's row lanes in LDS, then one slab row per workgroup
-        __shared__ int s_last;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (pass) __syncthreads();
@@ -703,37 +697,26 @@ __global__ void __launch_bounds__(NT) bn_rows_kernel(BnArgs a) {
                 for (int k = 0; k < V; ++k) a.slab[((size_t)blockIdx.x * 2 + pass) * a.C + c + k] = s_red[threadIdx.x * V + k];
             }
         }
-        // publish the slab row, then elect the last row group of this channel block (the threadFenceReduction pattern: the
-        // device-scope fence orders the stores above before the counter update and the loads below after it)
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(a.counter + blockIdx.y, 1u) == gridDim.x - 1;
-        __syncthreads();
-        if (s_last) {
-            __threadfence();
-            // 2 * cblk sums, each over gridDim.x partials IN INDEX ORDER.  NT / nsum threads share a sum (strided by `parts`), their
-            // partial results meet in LDS and are added in `part` order: the association is a function of the launch geometry only.
-            const int nsum = 2 * a.cblk;
-            const int parts = NT >= nsum ? NT / nsum : 1;
-            for (int base = 0; base < nsum; base += NT) {
-                const int sidx = base + (int)(threadIdx.x % (unsigned)min(nsum, NT)), part = threadIdx.x / min(nsum, NT);
-                const int pass = sidx / a.cblk, cc = blockIdx.y * a.cblk + sidx % a.cblk;
-                float t = 0.f;
-                if (sidx < nsum && cc < a.C && part < parts) {
-                    for (int j = part; j < (int)gridDim.x; j += parts) t += a.slab[((size_t)j * 2 + pass) * a.C + cc];
-                }
-                __syncthreads();
-                s_red[threadIdx.x] = t;
-                __syncthreads();
-                if (part == 0 && sidx < nsum && cc < a.C) {
-                    float tot = 0.f;
-                    for (int q = 0; q < parts; ++q) tot += s_red[q * min(nsum, NT) + sidx - base];
-                    a.sums[(pass ? a.C : 0) + cc] = tot;
-                }
-            }
-            if (threadIdx.x == 0) a.counter[blockIdx.y] = 0u;          // ready for the next launch on this workspace
-        }
     }
+}
+
+// slab -> sums: out[p * C + c] = sum over the `rows` row groups of slab[(j * 2 + p) * C + c], IN INDEX ORDER (bit-reproducible);
+// optionally the affine-gradient accumulation of the backward (acc_dbeta += sums[0..C), acc_dgamma += sums[C..2C)).
+__global__ void bn_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ sums, float* __restrict__ acc_dbeta,
+                                   float* __restrict__ acc_dgamma, int rows, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;             // 0 .. 2C
+    if (i >= 2 * C) return;
+    const int p = i / C, c = i - p * C;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;                    // four interleaved chains (fixed association), 4 loads in flight
+    int j = 0;
+    for (; j + 3 < rows; j += 4) {
+        t0 += slab[((size_t)(j + 0) * 2 + p) * C + c]; t1 += slab[((size_t)(j + 1) * 2 + p) * C + c];
+        t2 += slab[((size_t)(j + 2) * 2 + p) * C + c]; t3 += slab[((size_t)(j + 3) * 2 + p) * C + c];
+    }
+    for (; j < rows; ++j) t0 += slab[((size_t)j * 2 + p) * C + c];
+    const float tot = (t0 + t1) + (t2 + t3);
+    sums[i] = tot;
+    if (acc_dbeta) { if (p == 0) acc_dbeta[c] += tot; else acc_dgamma[c] += tot; }
 }
 
 // shifted sums -> (sum, sum of squared deviations):  sum = S1 + M*shift ;  ssd = S2 - S1^2 / M
@@ -784,15 +767,16 @@ static dim3 bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks, 
     else { fs2_set_error("bn: dtype"); return FS2_EDTYPE; } } while (0)
 #define BN_REDUCE_BLOCKS 256       /* statistics */
 #define BN_WS_ROWS 256             /* slab rows of a workspace >= row groups of any reducing launch (<= BN_*_BLOCKS) */
-#define BN_WS_COUNTERS 64          /* arrival counters (one per channel block; C <= 1024, >= 16-channel blocks) */
-// workspace of the reducing launches: [2C reduced sums][BN_WS_COUNTERS counters][BN_WS_ROWS x 2C partial sums]
-extern "C" int fs2_bn_ws_floats(int C) { return C > 0 ? 2 * C + BN_WS_COUNTERS + BN_WS_ROWS * 2 * C : 0; }
+// workspace of the reducing launches: [2C reduced sums][BN_WS_ROWS x 2C partial sums]
+extern "C" int fs2_bn_ws_floats(int C) { return C > 0 ? 2 * C + BN_WS_ROWS * 2 * C : 0; }
 static int bn_ws_bind(BnArgs& a, float* ws, int C, dim3 grid) {
     a.sums = ws;
-    a.counter = reinterpret_cast<unsigned*>(ws + 2 * C);
-    a.slab = ws + 2 * C + BN_WS_COUNTERS;
-    if (grid.x > BN_WS_ROWS || grid.y > BN_WS_COUNTERS) { fs2_set_error("bn: launch geometry %u x %u exceeds the workspace", grid.x, grid.y); return FS2_EINVAL; }
+    a.slab = ws + 2 * C;
+    if (grid.x > BN_WS_ROWS) { fs2_set_error("bn: launch geometry %u x %u exceeds the workspace", grid.x, grid.y); return FS2_EINVAL; }
     return FS2_OK;
+}
+static void bn_slab_sum(const BnArgs& a, dim3 grid, int C, float* acc_dbeta, float* acc_dgamma, hipStream_t stream) {
+    bn_slab_sum_kernel<<<fs2_cdiv(2 * C, 256), 256, 0, stream>>>(a.slab, a.sums, acc_dbeta, acc_dgamma, (int)grid.x, C);
 }
 #define BN_REDUCE_CBLK 64          /* channels per workgroup of the reducing modes */
 #define BN_BWD1_BLOCKS 256         /* backward sums: tanh + dropout hash per element -> needs every CU */
@@ -808,6 +792,7 @@ extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype
     dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
     if (int e = bn_ws_bind(a, stats, C, grid)) return e;
     BN_LAUNCH(0, 1024, grid);
+    bn_slab_sum(a, grid, C, nullptr, nullptr, stream);
     if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
     else bn_stats_fix_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats, M, C);
     FS2_CHECK_LAUNCH("bn_stats");
@@ -839,11 +824,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
 template <typename T>
 __global__ void bn_fix_finalize_kernel(const T* __restrict__ x, float* __restrict__ stats, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_rstd,
-                                       int M, int C, float eps, float momentum) {
+                                       int M, int C, float eps, float momentum, int rows) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    const float sh = Elem<T>::ld(x + c), s1 = stats[c], s2 = stats[C + c];
+    // the row groups' partial sums, added in index order (two interleaved chains per sum: fixed association)
+    const float* slab = stats + 2 * C;
+    float s1 = 0.f, s2 = 0.f, u1 = 0.f, u2 = 0.f;
+    int j = 0;
+    for (; j + 1 < rows; j += 2) {
+        s1 += slab[((size_t)j * 2) * C + c]; s2 += slab[((size_t)j * 2 + 1) * C + c];
+        u1 += slab[((size_t)(j + 1) * 2) * C + c]; u2 += slab[((size_t)(j + 1) * 2 + 1) * C + c];
+    }
+    if (j < rows) { s1 += slab[((size_t)j * 2) * C + c]; s2 += slab[((size_t)j * 2 + 1) * C + c]; }
+    s1 += u1; s2 += u2;
+    const float sh = Elem<T>::ld(x + c);
     const float sum = s1 + (float)M * sh, ssd = fmaxf(s2 - s1 * s1 / (float)M, 0.f);
     const float mean = sum / (float)M, var = ssd / (float)M;
     mean_rstd[c] = mean;
@@ -864,8 +859,8 @@ extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, float* running
     dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
     if (int e = bn_ws_bind(a, stats_ws, C, grid)) return e;
     BN_LAUNCH(0, 1024, grid);
-    if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
-    else bn_fix_finalize_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum);
+    if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum, (int)grid.x);
+    else bn_fix_finalize_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum, (int)grid.x);
     FS2_CHECK_LAUNCH("bn_train_stats");
     return FS2_OK;
 }
@@ -911,6 +906,7 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
     if (int e = bn_ws_bind(a, sums, C, grid)) return e;
     BN_LAUNCH(2, 1024, grid);
+    bn_slab_sum(a, grid, C, nullptr, nullptr, stream);
     vec = bn_vec(a, C, dtype);
     grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(3, 256, grid);
@@ -933,7 +929,7 @@ extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean
     dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
     if (int e = bn_ws_bind(a, sums, C, grid)) return e;
     BN_LAUNCH(2, 1024, grid);
-    a.acc_dbeta = dbeta_acc; a.acc_dgamma = dgamma_acc;
+    bn_slab_sum(a, grid, C, dbeta_acc, dgamma_acc, stream);       // ordered sums + the affine gradients (sum g = dbeta, sum g*xhat = dgamma)
     vec = bn_vec(a, C, dtype);
     grid = bn_geometry(a, M, C, 256, 2048, vec);
     BN_LAUNCH(3, 256, grid);

@@ -322,7 +322,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e
 
 
 def bn_workspace(C, device):
-    """workspace of the reducing BatchNorm launches (per-workgroup partial sums + arrival counters): zeroed here, once"""
+    """workspace of the reducing BatchNorm launches (reduced sums + per-workgroup partial sums, summed in index order)"""
     return torch.zeros(_lib.load().fs2_bn_ws_floats(C), device=device, dtype=torch.float32)
 
 

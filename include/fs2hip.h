@@ -154,9 +154,9 @@ int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_
 int fs2_ln_bwd_reduce(const float* partial_ws, int C, float* dgamma /*+=*/, float* dbeta /*+=*/, fs2_stream_t stream);
 
 /* ---- BatchNorm1d (+tanh, +dropout) of PostNet: transformer/Layers.py:129-137 ------------------------ */
-/* Column sums are bit-reproducible: every reducing launch stores per-workgroup partial sums in a workspace and the last
- * workgroup adds them in index order (no float atomics).  A BN workspace holds fs2_bn_ws_floats(C) floats; zero it ONCE when it
- * is allocated (its arrival counters must be zero on entry; the kernels leave them zero).  Its first 2C floats receive the sums. */
+/* Column sums are bit-reproducible: every reducing launch stores per-workgroup partial sums in a workspace and a second tiny
+ * launch adds them in index order (no float atomics, no device-scope fences).  A BN workspace holds fs2_bn_ws_floats(C)
+ * floats (any contents); its first 2C floats receive the sums. */
 int fs2_bn_ws_floats(int C);
 int fs2_bn_stats(const void* x, float* stats /*workspace; [0,2C) = sum | sum of squared deviations*/, int M, int C, int dtype,
                  fs2_stream_t stream);
