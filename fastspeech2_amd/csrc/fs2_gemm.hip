@@ -1611,6 +1611,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) conv_wgrad_bf16_kern
     else wgrad_bf16_body<(REM ? REM : 1), NW>(a, smem, tile_n, tile_c, a.g3 * NT);
 }
 
+// the largest workspace any launch plans for (one slab beyond it: no workspace, the atomic path): callers allocate this once
+extern "C" int fs2_conv_wgrad_ws_cap(void) { return (int)FS2_WGRAD_WS_CAP; }
 extern "C" int fs2_conv_wgrad_ws_bytes(int M, int N, int Cin, int S, int taps, int dil, int has_lens, int dtype) {
     if (dtype != FS2_BF16 || M <= 0 || N <= 0 || Cin <= 0 || S <= 0 || taps <= 1) return 0;   // (one-tap launches: see conv_wgrad_impl)
     const WgradPlan p = wgrad_plan(M, N, Cin, S, taps, dil, has_lens != 0, true);

@@ -19,6 +19,7 @@ struct WgradArgs {
 //   tiles = 128 x 128 output tiles x tap groups; units = 64-row K-tiles (never straddling a sequence)
 // With a slab workspace a split costs one plain store of its tile + its share of the finalize pass (no atomics), so the depth is
 // chosen to fill the chip ONCE (~1 workgroup per CU) with at least 8 K-tiles per workgroup; the slabs are capped at 96 MB.
+#define FS2_WGRAD_WS_CAP (96L << 20)        /* bytes: exported as fs2_conv_wgrad_ws_cap() - the one place the cap is written */
 struct WgradPlan { int tiles, units, ups, splits, g_first, n_first, n_rest, share; };
 static inline WgradPlan wgrad_plan(int M, int N, int Cin, int S, int taps, int dil, bool has_lens, bool slab) {
     WgradPlan p = {};
@@ -43,7 +44,7 @@ static inline WgradPlan wgrad_plan(int M, int N, int Cin, int S, int taps, int d
         const long max_by_units = p.units / 8 > 0 ? p.units / 8 : 1;
         if (want > max_by_units) want = max_by_units;
         const long slab_bytes = ((long)N * taps * Cin + N) * 4;
-        const long max_by_ws = (96L << 20) / slab_bytes > 0 ? (96L << 20) / slab_bytes : 1;
+        const long max_by_ws = FS2_WGRAD_WS_CAP / slab_bytes > 0 ? FS2_WGRAD_WS_CAP / slab_bytes : 1;
         if (want > max_by_ws) want = max_by_ws;
         if (want < 1) want = 1;
         p.ups = (int)((p.units + want - 1) / want);

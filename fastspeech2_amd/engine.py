@@ -81,6 +81,10 @@ class Engine:
         self.gemm_lens_fwd = None       # None: per batch (skippable-tile fraction >= lens_skip_min); True / False: forced
         self.gemm_lens_bwd = None
         self.lens_skip_min = 0.10
+        # explicit host copies of the NEXT batch's lengths (FastSpeech2.set_length_hint): take precedence over the copies riding on
+        # the device tensors (`_fs2_host`, lost by .to() / clone / slicing, stale when a static buffer is refilled with copy_)
+        self.length_hint = None
+        self._wgrad_ws = ops.WgradWorkspaces()      # split-K scratch of the weight gradients: lives and dies with this engine
         self.fuse_proj_ln = False       # see _proj_ln: the one-launch form is measured slower at the bench shape
         self._pack_pending = False
         self._bn_ws = {}
@@ -400,12 +404,12 @@ class Engine:
             gw = gw.permute(0, 2, 1)            # tap-major storage of the gradient
         side = self._side
         if side is None:
-            ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
+            ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb, ws_owner=self._wgrad_ws)
             return
         side.wait_stream(self._main)            # dy was produced on the main stream
         with ops.pinned_stream(side):           # (no allocation happens inside: only the launch needs the side stream)
             self._ln_flush()
-            ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb)
+            ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb, ws_owner=self._wgrad_ws)
         self._side_keep.append((dy, x))         # the caching allocator must not recycle them before the join
 
     def _ln_bwd(self, z, dout, gamma, lens, mean, rstd, gw, gb, B, S, **kw):
@@ -449,6 +453,7 @@ class Engine:
                 with ops.pinned_stream(self._side):
                     self._ln_flush()
             self._main.wait_stream(self._side)
+            self._wgrad_ws.release_retired()        # (main-stream allocations from here on are ordered behind the side stream's work)
         self._side_keep = []
 
     def _fft_fwd(self, W, pre, x, lens, B, S, n_head, p, seed_dev, site, keep):
@@ -584,7 +589,8 @@ class Engine:
         p_pn = 0.5 if drop else 0.0
         st.counts = torch.empty(2, device=self.device, dtype=torch.float32)
         src_lens32, st.src_masks, src_lens32._fs2_tmap = ops.lens_prep(st.src_lens, B, L, st.counts[0:1])
-        src_lens32._fs2_skip = self._skip_fraction(getattr(st.src_lens, "_fs2_host", None), L)
+        hint, self.length_hint = self.length_hint, None     # consumed by this forward
+        src_lens32._fs2_skip = self._skip_fraction(hint[0] if hint else getattr(st.src_lens, "_fs2_host", None), L)
 
         # ---- encoder (transformer/Models.py:73-100)
         n_head = self.tc["encoder_head"]
@@ -650,7 +656,8 @@ class Engine:
         st.mel_lens_out, st.Tdec = mel_len, Tdec
         dec_lens32, st.mel_masks, dec_lens32._fs2_tmap = ops.lens_prep(mel_len, B, Tdec, st.counts[1:2])
         # (training: the frame counts equal the batch's mel_lens - sum of the target durations - whose host copy came with the batch)
-        dec_lens32._fs2_skip = self._skip_fraction(getattr(st.mel_lens, "_fs2_host", None) if st.d_t is not None else None, Tdec)
+        dec_lens32._fs2_skip = self._skip_fraction(((hint[1] if hint and hint[1] is not None else getattr(st.mel_lens, "_fs2_host", None))
+                                                    if st.d_t is not None else None), Tdec)
         frame_level = (not pitch_phone) or (not energy_phone)
         pe_dec = self._pe(P["decoder.position_enc"], Tdec)
         sv.x_lr_in = None

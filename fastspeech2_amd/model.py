@@ -15,6 +15,8 @@ import json
 import math
 import os
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -334,6 +336,18 @@ class FastSpeech2(nn.Module):
             # eval-mode [mean | rstd] cache is dropped on every mode switch - eval() after training always rebuilds it
             self._engine._bn_eval.clear()
         return super().train(mode)
+
+    def set_length_hint(self, src_lens_host, mel_lens_host=None):
+        """Host copies (numpy / list / CPU tensor) of the NEXT forward's src_lens and mel_lens.  The reference's positional forward
+        only carries device tensors; whether the contractions skip wholly padded tiles (Engine.lens_skip_min) is decided on the
+        host, without a device round trip, from these - or, when this is not called, from the copy `utils.to_device` attaches to
+        the lengths tensors it makes.  Neither present: no tile skipping (results are identical either way).  A captured hipGraph
+        keeps the choice made at capture time."""
+        if self._engine is None and next(self.parameters()).is_cuda:
+            self._ensure_flat(next(self.parameters()).device)
+        if self._engine is not None:
+            self._engine.length_hint = (None if src_lens_host is None else np.asarray(src_lens_host),
+                                        None if mel_lens_host is None else np.asarray(mel_lens_host))
 
     # ------------------------------------------------------------------ forward (reference signature)
     def forward(self, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,

@@ -173,29 +173,42 @@ def tile_map(lens, B, S):
     return out
 
 
-_wgrad_ws = {}
-_wgrad_ws_retired = []
-_WGRAD_WS_MIN = 100 << 20            # the planner caps a launch's slabs at 96 MB: one allocation per stream covers every shape
+class WgradWorkspaces:
+    """split-K scratch of the weight-gradient launches, one buffer per stream (launches on a stream run in order, so they share
+    it), allocated once at the library's own cap (fs2_conv_wgrad_ws_cap: no shape asks for more).  OWNED: an Engine holds one and
+    it dies with the engine; `ops` keeps a module-level one only for direct calls (tests, tools).  Should a larger buffer ever be
+    needed, the old one is RETIRED, not freed, until `release_retired` is called after the streams have been joined: it was
+    allocated from the pool of torch's current stream but is used by kernels queued on another (the engine's side stream);
+    handing it back early let the caching allocator give its memory to the next main-stream tensor while a queued weight-gradient
+    kernel still wrote slabs there (round-3 finding: non-finite gradients on the first 2-rank step, tools/dbg_ddp.py)."""
+
+    def __init__(self):
+        self._ws = {}
+        self._retired = []
+
+    def get(self, device, stream_handle, nbytes):
+        key = (device.index, stream_handle)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 4 < nbytes:
+            if ws is not None:
+                self._retired.append(ws)
+            ws = torch.empty(max(nbytes, _lib.load().fs2_conv_wgrad_ws_cap()) // 4 + 4, device=device, dtype=torch.float32)
+            self._ws[key] = ws
+        return ws
+
+    def release_retired(self):
+        """call only when every stream that used the retired buffers has been joined / synchronised"""
+        self._retired.clear()
+
+
+_default_wgrad_ws = WgradWorkspaces()
 
 
 def wgrad_workspace(device, stream_handle, nbytes):
-    """split-K scratch of the weight-gradient launches of ONE stream (launches on a stream run in order, so they share it).
-    Allocated once per stream at the planner's cap.  Should a larger one ever be needed, the old buffer is RETIRED, not freed:
-    it was allocated from the pool of torch's current stream (the step's main stream) but is used by kernels queued on
-    `stream_handle` (the engine's side stream); handing it back would let the caching allocator give its memory to the next
-    main-stream tensor while a queued weight-gradient kernel still writes slabs there (round-3 finding: the first step of a run
-    grew the workspace three times and non-finite gradients appeared in whatever was allocated next - tools/dbg_ddp.py)."""
-    key = (device.index, stream_handle)
-    ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        if ws is not None:
-            _wgrad_ws_retired.append(ws)
-        ws = torch.empty(max(nbytes, _WGRAD_WS_MIN) // 4 + 4, device=device, dtype=torch.float32)
-        _wgrad_ws[key] = ws
-    return ws
+    return _default_wgrad_ws.get(device, stream_handle, nbytes)
 
 
-def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None, dbias=None, use_ws=True):
+def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None, dbias=None, use_ws=True, ws_owner=None):
     """dw: tap-major (Cout, k, Cin) fp32 += dy^T * shifted x;  dbias (Cout,) fp32 += column sums of dy (same pass).
     bf16: split-K through a per-stream workspace (slab stores + one finalize launch, no atomics) unless use_ws is False."""
     M, N = dy.shape
@@ -204,7 +217,7 @@ def conv_wgrad(dy, x, dw, S, taps=1, dil=1, pad=0, lens=None, dbias=None, use_ws
         need = _lib.load().fs2_conv_wgrad_ws_bytes(M, N, Cin, S, taps, dil, int(lens is not None), BF16)
         if need > 0:
             h = _stream()
-            ws = wgrad_workspace(dy.device, h, need)
+            ws = (ws_owner or _default_wgrad_ws).get(dy.device, h, need)
             if PROFILE is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

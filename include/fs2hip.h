@@ -113,6 +113,7 @@ int fs2_conv_wgrad(const void* dY, long lddy, const void* X, long ldx, float* dW
  * the same shape, 16-byte aligned, any contents, not shared by launches that may run concurrently; NULL or too small = the
  * atomic path of fs2_conv_wgrad.  bf16 only (fp32 ignores ws).  fs2_conv_wgrad_ws_bytes returns a size, not a status. */
 int fs2_conv_wgrad_ws_bytes(int M, int N, int Cin, int S, int taps, int dil, int has_lens, int dtype);
+int fs2_conv_wgrad_ws_cap(void);     /* upper bound of fs2_conv_wgrad_ws_bytes over all shapes that get a workspace at all (a size, not a status) */
 int fs2_conv_wgrad_ws(const void* dY, long lddy, const void* X, long ldx, float* dW, float* dbias, const int32_t* lens, int M,
                       int N, int Cin, int S, int taps, int dil, int pad, int dtype, float* ws, long ws_bytes, fs2_stream_t stream);
 /* out[n] += sum_m x[m][n]  (bias gradients) */
