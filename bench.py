@@ -671,6 +671,27 @@ def main():
                                              for v2, d in sorted(by.items())},
                         "family_achieved": round(fam, 1), "family_frac": round(fam / peak, 4), "family_ms_per_step": round(tot_ms / 3, 3),
                         "step_frac_of_peak": round(value / world * train_flop_per_frame(args) / (peak * 1e12), 4)}
+            # what the matrix pipes SUSTAIN on this chip under its power management: a bare back-to-back bf16 MFMA stream on every
+            # SIMD (fs2_mfma_calibrate, ~0.5 ms), timed right here.  `peak` stays the nominal 2.5 PF; this says how much of the
+            # distance to it is the clock (MI355X_MICROARCH.md "DVFS give-back") rather than the kernel.
+            try:
+                import ctypes
+                sink = torch.zeros(1, device=device)
+                fl_ = ctypes.c_double(0.0)
+                ts = []
+                for _ in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops._lib.call("fs2_mfma_calibrate", 4000, sink.data_ptr(), ctypes.byref(fl_), ops._stream())
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                sus = fl_.value / (sorted(ts[1:])[1] * 1e-3) / 1e12
+                roofline["mfma_sustained"] = {"tflops": round(sus, 1), "frac_of_nominal_peak": round(sus / peak, 4),
+                                              "kernel_frac_of_sustained": round(ach / sus, 4),
+                                              "how": "bare v_mfma_f32_32x32x16_bf16 stream, one wave per SIMD on every CU, non-zero operands, median of 3"}
+            except Exception as e:  # a measurement aid: never fails the line
+                print(f"[bench] mfma calibration failed ({type(e).__name__}: {e})", file=sys.stderr)
             # the weight-gradient kernels of the same replay (side stream off: each duration is the kernel's own).  They run on
             # the side stream in the timed step and are the largest block of device time after the contractions above.
             wrec = prof.get("conv_wgrad", [])

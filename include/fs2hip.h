@@ -74,6 +74,10 @@ int fs2_conv_gemm_splitk(const void* X, long ldx, const void* Wpacked, const flo
                          long ldy, const int32_t* lens, const int32_t* tile_map, float* ws, int ksplit, int M, int N, int Cin,
                          int S, int taps, int dil, int pad, int act, float slope, float out_scale, int dtype,
                          fs2_stream_t stream);
+/* Measurement aid: a back-to-back v_mfma_f32_32x32x16_bf16 stream on every SIMD of the chip (one 256-thread workgroup per CU,
+ * iters x 8 MFMAs per wave); *flops receives the FLOPs of the launch.  bench.py times it to report what the matrix pipes SUSTAIN
+ * under the chip's power management beside the nominal peak.  sink: one float of device memory (never written in practice). */
+int fs2_mfma_calibrate(int iters, float* sink, double* flops, fs2_stream_t stream);
 /* The 512 x 128 tall-tile kernel (fs2_gemm_t.hip) by name: an experiment kept for its parity test and A/B tool - the default
  * dispatch does not pick it (round 4: slower than the 256 x 128 persistent kernel at every shape of the model).  bf16, taps 5 or 9,
  * dil 1, Cin % 64 == 0, no lens, >= one tile per CU; FS2_EINVAL otherwise.  tail_ws: fs2_conv_gemm_tail_ws_bytes() or NULL. */

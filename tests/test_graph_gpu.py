@@ -56,7 +56,11 @@ def test_graph_replay_matches_eager_steps(dev, side_stream):
     noise = float((me2 - me).norm() / me.norm())
     rel = float((mg - me).norm() / me.norm())
     print(f"side_stream={side_stream}: eager-vs-eager {noise:.2e}, graph-vs-eager {rel:.2e}")
-    assert rel < 4 * noise + 4e-3, (rel, noise)
+    # round 4: with bit-reproducible BatchNorm sums two eager runs agree to 4e-7 .. 5e-5 and the captured run sits 1e-6 .. 7e-4 from
+    # them (fp32 atomics of the one-tap weight gradients, amplified by Adam's g / sqrt(v) on near-zero gradients over 7 steps:
+    # tools/dbg_single_stream.py, profiles/r04s_dbg_single.log - 5e-7 after ONE step in every stream mode).  The bar sits below the
+    # 2.8e-3 a forked capture produced in round 3.
+    assert rel < 4 * noise + 1.5e-3, (rel, noise)
     for k in bne:
         assert torch.allclose(bne[k].float(), bng[k].float(), rtol=1e-5, atol=1e-6), k
     assert float((pg - pe).abs().max()) < 1e-5                          # 7 warm-up-rate Adam steps: |dp| <= ~2e-6 each
