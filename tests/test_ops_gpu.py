@@ -130,12 +130,12 @@ def test_weight_gradient_workspace_path_edge_cases(dev, Bq, S, Cin, Cout, k, pad
         binit = torch.randn(Cout, generator=g).to(dev)
         outs = []
         for rep in range(2):
-            for key, ws in list(ops._wgrad_ws.items()):
+            for key, ws in list(ops._default_wgrad_ws._ws.items()):
                 ws.fill_(float("nan"))
             dw, db = init.clone(), binit.clone()
             ops.conv_wgrad(dy, x, dw, S, taps=k, pad=pad, lens=ld, dbias=db)
             if rep == 0:                                                   # (first call may have just created the workspace: poison + redo)
-                for key, ws in list(ops._wgrad_ws.items()):
+                for key, ws in list(ops._default_wgrad_ws._ws.items()):
                     ws.fill_(float("nan"))
                 dw, db = init.clone(), binit.clone()
                 ops.conv_wgrad(dy, x, dw, S, taps=k, pad=pad, lens=ld, dbias=db)
