@@ -953,6 +953,9 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
 // Which kernel a launch description dispatches to: a PURE function of the description (no state, no environment in the
 // shipped build), shared by fs2_conv_gemm and by the query entry point fs2_conv_gemm_variant that bench.py uses to attribute
 // its HIP-event durations to the kernel names rocprofv3 reports.
+// defined in fs2_gemm_s.hip
+bool fs2_conv_gemm_s_ok(const ConvGemmArgs& a, int dtype);
+void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream);
 // defined in fs2_gemm_t.hip
 bool fs2_conv_gemm_t_can(const ConvGemmArgs& a, bool has_map, int dtype);
 bool fs2_conv_gemm_t_ok(const ConvGemmArgs& a, bool has_map, int dtype, bool have_tail_ws);
@@ -989,6 +992,8 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, b
     p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= 32;
     // wide-tile one-tap kernel (fs2_gemm_w.hip): N a multiple of 256 - the Linear layers of the FFT blocks and their data gradients
     static const int w_on = fs2_dev_env("FS2_GEMM_W", 1);
+    // streaming kernel with the weights in registers (fs2_gemm_s.hip): the K = 256 Linear layers and data gradients
+    if (!skinny && fs2_conv_gemm_s_ok(a, dtype)) { p.variant = FS2_GEMM_STREAM_K256; return p; }
     if (w_on && !skinny && fs2_conv_gemm_w_ok(a, has_map, dtype)) { p.variant = FS2_GEMM_WIDE_1TAP; return p; }
     // tall-tile all-consumer kernel (fs2_gemm_t.hip): the large convolutions without lens, when its 512-row tiles fill the chip
     if (!skinny && fs2_conv_gemm_t_ok(a, has_map, dtype, has_tail_ws)) { p.variant = FS2_GEMM_TALL; return p; }
@@ -1038,6 +1043,8 @@ static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* b
     const GemmPick pk = conv_gemm_pick(a, dtype, tile_map != nullptr, tail_ws != nullptr);
     if (pk.variant == FS2_GEMM_TALL) {
         fs2_conv_gemm_t_launch(a, stream, tail_ws);
+    } else if (pk.variant == FS2_GEMM_STREAM_K256) {
+        fs2_conv_gemm_s_launch(a, stream);
     } else if (pk.variant == FS2_GEMM_SKINNY) {
         if (Cin == 32) launch_skinny<32>(a, stream);
         else if (Cin == 64) launch_skinny<64>(a, stream);

@@ -96,6 +96,7 @@ int fs2_conv_gemm_tall(const void* X, long ldx, const void* Wpacked, const float
 #define FS2_GEMM_WIDE_1TAP 7 /* conv_gemm_w_kernel: persistent 256x256 tiles, every wave loads and multiplies (taps == 1, N % 256 == 0) */
 #define FS2_GEMM_TALL 8    /* conv_gemm_t_kernel: persistent 512x128 tiles, eight self-loading consumer waves - never returned by the
                               shipped dispatch (see fs2_conv_gemm_tall) */
+#define FS2_GEMM_STREAM_K256 9 /* conv_gemm_s_kernel: one tap, K = 256, N % 256 == 0 - weights in registers, X streamed through LDS (HBM-bound) */
 int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens, int has_map, int M, int N, int Cin, int S, int taps,
                           int dil, int in_act, float in_slope, int dtype);
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
