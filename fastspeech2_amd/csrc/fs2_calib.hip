@@ -47,3 +47,19 @@ extern "C" int fs2_mfma_calibrate(int iters, float* sink, double* flops, hipStre
     *flops = (double)cus * 4.0 * (double)iters * 8.0 * (2.0 * 32 * 32 * 16);
     return FS2_OK;
 }
+
+#ifdef FS2_DEV
+// dev aid: which SIMD does wave i of a workgroup of `threads` threads land on?  out[block * 16 + wave] = HW_ID
+__global__ void wave_map_kernel(int* __restrict__ out) {
+    extern __shared__ unsigned char smem_[];
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = (int)id;
+}
+extern "C" int fs2_dev_wave_map(int* out, int blocks, int threads, int lds, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)wave_map_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    wave_map_kernel<<<blocks, threads, lds, stream>>>(out);
+    FS2_CHECK_LAUNCH("wave_map");
+    return FS2_OK;
+}
+#endif

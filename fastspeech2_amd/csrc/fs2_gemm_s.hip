@@ -26,7 +26,8 @@
 
 static constexpr int S_TM = 64, S_K = 256, S_NBUF = 4;
 static constexpr int S_TILE_BYTES = S_TM * S_K * 2;      // 32 KB
-static constexpr int S_LDS = S_NBUF * S_TILE_BYTES;      // 128 KB
+static constexpr int S_MAXB = 1024;                      // lens[] staged in LDS
+static constexpr int S_LDS = S_NBUF * S_TILE_BYTES + S_MAXB * 4 + 256 * 4;      // 133 KB (+ the lengths, + the workgroup's bias line)
 static constexpr int S_NLOAD = 2;                        // loader waves
 static constexpr int S_CONS = 8;                         // consumer waves (32 output columns each)
 static constexpr int S_THREADS = (S_CONS + S_NLOAD) * 64;
@@ -39,19 +40,23 @@ __device__ __forceinline__ void s_barrier_mem() {
 }
 
 // epilogue of one wave: 64 rows x 32 columns from the transposed accumulators (layout as p_epilogue, one column block)
-template <int ACT>
-__device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][1], int m0, int nbase, int fl, int fh) {
+// No global LOAD may sit behind the previous tile's stores on a tile's critical path (the compiler waits with vmcnt(0) for a
+// loaded value once stores are pending too - loads and stores can retire out of order - so every tile would pay the store latency:
+// the first cut of this epilogue ran 5 us per 64-row tile, waves parked 66 %, r04v_s_pmc_mfma.md): the bias line sits in registers
+// (bb), the lengths in LDS (lens_s), and the residual / gate operand of THIS tile (rr) was requested before the tile's MFMAs.
+template <int ACT, int ABL>
+__device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][1], int m0, int nbase, int fl, int fh,
+                                           const float* bias_s, const int32_t* lens_s, const uint4 (&rr)[2][2]) {
     bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
-    const bf16_t* R = reinterpret_cast<const bf16_t*>(a.R);
+    const bool has_r = a.R != nullptr;
     const bool gate = a.act == FS2_ACT_GATE;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int m = m0 + mb * 32 + fl;
         const bool rowok = m < a.M;
         bool padrow = false;
-        if (a.lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= a.lens[b]; }
+        if (a.lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
         bf16_t* yrow = Y + (size_t)m * a.ldy;
-        const bf16_t* rrow = R ? R + (size_t)m * a.ldr : nullptr;
 #pragma unroll
         for (int nb = 0; nb < 1; ++nb) {
             float c[2][8];
@@ -67,18 +72,10 @@ __device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
                 const int n = nbase + nb * 32 + ch * 16 + fh * 8;
                 if (!rowok) continue;
                 float v[8];
-                if (a.bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n), b1 = *reinterpret_cast<const float4*>(a.bias + n + 4);
-                    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(c[ch][e] + bb[e], a.slope);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(c[ch][e], a.slope);
-                }
-                if (rrow) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(rrow + n);
-                    const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr);
+                for (int e = 0; e < 8; ++e) v[e] = act_ct<ACT>(c[ch][e] + bias_s[ch * 8 + e], a.slope);   // (zeros without a bias)
+                if (has_r) {
+                    const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr[mb][ch]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
@@ -98,19 +95,33 @@ __device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
                 uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<uint4*>(yrow + n) = o;
+                if (ABL != 1 || o.x == 0x12345678u) *reinterpret_cast<uint4*>(yrow + n) = o;
             }
         }
     }
 }
 
-// grid (stripes, N / 256): workgroup (x, y) walks the 64-row tiles x, x + stripes, ... of column group y
-__global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, int ntiles) {
+// grid stripes * (N / 256), 1-D: a workgroup walks the 64-row tiles stripe, stripe + stripes, ... of one 256-column group
+// ABL (dev builds only, never launched by the product): 1 = no stores, 2 = no epilogue, 3 = no MFMA loop, 4 = consumers only pass
+// the barriers.  SKEW: the second wave of each SIMD (waves 4..7) runs its epilogue one barrier LATE, so that on every SIMD one
+// wave's MFMAs overlap the other's epilogue VALU work (the barrier per tile otherwise keeps all waves in the same phase).  Measured
+// (r04x_s_skew.log; wave i sits on SIMD {3,0,2,1}[i % 4], so waves w and w + 4 do share one): no gain from any pairing - the kernel
+// is bound by bytes moved per CU, not by issue slots - so the product launches SKEW = 0 and the modes stay a dev switch.
+template <int ABL, int SKEW>
+__global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, int ntiles, int stripes, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int stripes = gridDim.x;
-    const int my_tiles = (ntiles - (int)blockIdx.x + stripes - 1) / stripes;      // >= 1: the launcher keeps stripes <= ntiles
+    // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, and the `groups` workgroups that stream the SAME rows
+    // (one per 256-column group) must share an L2, or every X tile crosses the fabric `groups` times: id -> (xcd = id % 8,
+    // slot = id / 8), column group = slot % groups, row stripe = (slot / groups) * 8 + xcd.  (stripes is a multiple of 8, or
+    // groups == 1, by the launcher.)
+    const int bid = (int)blockIdx.x;
+    const int slot = bid >> 3;
+    const int col_group = groups == 1 ? 0 : slot % groups;
+    const int stripe = groups == 1 ? bid : (slot / groups) * 8 + (bid & 7);
+    const int my_tiles = (ntiles - stripe + stripes - 1) / stripes;
+    if (my_tiles <= 0) return;                               // (whole workgroup: a stripe past the last tile)
     const unsigned smem_u = lds_addr(smem);
 
     if (wave >= S_CONS) {
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
         const unsigned ldx2 = (unsigned)(a.ldx * 2);
         const int hi = lane >> 5, pos = lane & 31;
         auto issue = [&](int t) {                            // tile t of this workgroup -> buffer t % 3; 16 pieces of 2 rows
-            const int m0 = ((int)blockIdx.x + t * stripes) * S_TM;
+            const int m0 = (stripe + t * stripes) * S_TM;
             const unsigned dst0 = smem_u + (unsigned)((t % S_NBUF) * S_TILE_BYTES);
 #pragma unroll
             for (int i = 0; i < 32 / S_NLOAD; ++i) {
@@ -147,7 +158,7 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
 
     // ------------------------------------------------------------------ consumer waves
     const int fl = lane & 31, fh = lane >> 5;
-    const int nbase = (int)blockIdx.y * 256 + wave * 32;
+    const int nbase = col_group * 256 + wave * 32;
     // the wave's weight slice, once, straight into registers: B fragment ks = rows nbase + fl, k = 16 ks + 8 fh .. + 8
     u32x4 Wf[16];
     {
@@ -155,27 +166,72 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) Wf[ks] = *reinterpret_cast<const u32x4*>(wrow + ks * 32);
     }
+    // the workgroup's bias line and the lengths in LDS (written before the first barrier, which every wave passes before any epilogue).
+    // bias layout: [wave][half][run][8] so that a lane reads its two 8-column runs as 16 consecutive floats
+    int32_t* lens_s = reinterpret_cast<int32_t*>(smem + S_NBUF * S_TILE_BYTES);
+    float* bias_all = reinterpret_cast<float*>(smem + S_NBUF * S_TILE_BYTES + S_MAXB * 4);
+    if (tid < 256) {
+        const int w_ = tid >> 5, r_ = tid & 31, ch_ = r_ >> 4, fh_ = (r_ >> 3) & 1, e_ = r_ & 7;
+        bias_all[w_ * 32 + fh_ * 16 + ch_ * 8 + e_] = a.bias ? a.bias[col_group * 256 + tid] : 0.f;
+    }
+    if (a.lens) {
+        const int Bq = a.M / a.S;
+        for (int i = tid; i < Bq; i += S_CONS * 64) lens_s[i] = a.lens[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const float* bias_s = bias_all + wave * 32 + fh * 16;
+    const bf16_t* Rb = reinterpret_cast<const bf16_t*>(a.R);
     const unsigned arow = (unsigned)(fl * 512);              // byte offset of the lane's row (second row block: + 32 rows)
-    const unsigned akey = (unsigned)(fl & 15);
+    unsigned akey = (unsigned)(fl & 15);
+    const bool late = SKEW == 1 ? wave >= 4 : SKEW == 2 ? (wave & 1) != 0 : SKEW == 3 ? ((wave >> 1) & 1) != 0 : false;
+    f32x16 acc[2][1];
+    uint4 rr[2][2];
+    int m0 = 0;
+#define S_EPILOGUE()                                                                                                            \
+    do {                                                                                                                        \
+        if (ABL == 2 || ABL == 4) {                                                                                             \
+            float sink = 0.f;                                                                                                   \
+            for (int i_ = 0; i_ < 2; ++i_)                                                                                      \
+                for (int r_ = 0; r_ < 16; ++r_) sink += acc[i_][0][r_];                                                         \
+            if (sink == 123.456f) reinterpret_cast<float*>(a.Y)[0] = sink;                                                      \
+        } else {                                                                                                                \
+            FS2_ACT_DISPATCH(a.act, (s_epilogue<ACT, ABL>(a, acc, m0, nbase, fl, fh, bias_s, lens_s, rr)));                     \
+        }                                                                                                                       \
+    } while (0)
     for (int t = 0; t < my_tiles; ++t) {
         s_barrier_mem();                                     // tile t has landed (all loader pieces)
+        if (ABL == 4) continue;
+        if (late && t > 0) S_EPILOGUE();                     // (tile t - 1's, from registers only)
+        asm volatile("" : "+v"(akey));                       // (keeps the 16 swizzled column offsets from being hoisted into 16 registers:
+                                                             //  the budget is 168 with 10 waves, and a spill is a scratch LOAD per tile)
         const unsigned char* buf = smem + (t % S_NBUF) * S_TILE_BYTES;
-        f32x16 acc[2][1];
+        m0 = (stripe + t * stripes) * S_TM;
+        // this tile's residual / gate operand: requested NOW, used after the MFMAs
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int m = min(m0 + mb * 32 + fl, a.M - 1);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+                rr[mb][ch] = Rb ? *reinterpret_cast<const uint4*>(Rb + (size_t)m * a.ldr + nbase + ch * 16 + fh * 8) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        if (ABL != 3) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const unsigned coff = ((unsigned)(2 * ks + fh) ^ akey) << 4;
-            const u32x4 a0 = *reinterpret_cast<const u32x4*>(buf + arow + coff);
-            const u32x4 a1 = *reinterpret_cast<const u32x4*>(buf + arow + 32 * 512 + coff);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[ks]), __builtin_bit_cast(bf16x8, a0), acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[ks]), __builtin_bit_cast(bf16x8, a1), acc[1][0], 0, 0, 0);
+            for (int ks = 0; ks < 16; ++ks) {
+                const unsigned coff = ((unsigned)(2 * ks + fh) ^ akey) << 4;
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(buf + arow + coff);
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(buf + arow + 32 * 512 + coff);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[ks]), __builtin_bit_cast(bf16x8, a0), acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[ks]), __builtin_bit_cast(bf16x8, a1), acc[1][0], 0, 0, 0);
+            }
         }
-        const int m0 = ((int)blockIdx.x + t * stripes) * S_TM;
-        FS2_ACT_DISPATCH(a.act, (s_epilogue<ACT>(a, acc, m0, nbase, fl, fh)));
+        if (!late) S_EPILOGUE();
     }
+    if (late && ABL != 4) S_EPILOGUE();
+#undef S_EPILOGUE
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
@@ -197,6 +253,7 @@ static int s_cu_count() {
 bool fs2_conv_gemm_s_ok(const ConvGemmArgs& a, int dtype) {
     if (dtype != FS2_BF16 || a.taps != 1 || a.in_act != FS2_ACT_NONE) return false;
     if (a.Cin != S_K || a.N % 256 != 0 || a.N > 256 * 64 || !a.vec_ok || a.ldx % 8 != 0) return false;
+    if (a.lens && a.M / a.S > S_MAXB) return false;
     if ((double)a.M * a.ldx * 2 >= 4.0e9) return false;
     static const int on = fs2_dev_env("FS2_GEMM_S", 1);               // dev A/B: 0 = off
     if (!on) return false;
@@ -205,10 +262,34 @@ bool fs2_conv_gemm_s_ok(const ConvGemmArgs& a, int dtype) {
 
 void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream) {
     static Fs2DevOnce once;
-    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS); });
+    once.run([&] {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+#ifdef FS2_DEV
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+#endif
+    });
     const int ntiles = fs2_cdiv(a.M, S_TM), groups = a.N / 256;
-    int stripes = s_cu_count() / groups;                    // one workgroup per CU (96 KB of LDS + 256 registers per wave)
-    if (stripes < 1) stripes = 1;
-    if (stripes > ntiles) stripes = ntiles;
-    conv_gemm_s_kernel<<<dim3((unsigned)stripes, (unsigned)groups), S_THREADS, S_LDS, stream>>>(a, ntiles);
+    // one workgroup per CU (133 KB of LDS); with several column groups the stripe count is a multiple of 8 (see the kernel's map)
+    int stripes = s_cu_count() / groups;
+    if (groups > 1) stripes = stripes / 8 * 8;
+    if (stripes > ntiles) stripes = groups > 1 ? ntiles / 8 * 8 : ntiles;
+    if (stripes < 8) { stripes = 8; }                        // (tiles past ntiles: a stripe with no tile returns at once)
+    const dim3 grid((unsigned)(stripes * groups));
+#ifdef FS2_DEV
+    static const int abl = fs2_dev_env("FS2_S_ABL", 0), skew = fs2_dev_env("FS2_S_SKEW", 0);
+    if (skew == 1) { conv_gemm_s_kernel<0, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+    if (skew == 2) { conv_gemm_s_kernel<0, 2><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+    if (skew == 3) { conv_gemm_s_kernel<0, 3><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+    if (abl == 1) { conv_gemm_s_kernel<1, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+    if (abl == 2) { conv_gemm_s_kernel<2, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+    if (abl == 3) { conv_gemm_s_kernel<3, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+    if (abl == 4) { conv_gemm_s_kernel<4, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+#endif
+    conv_gemm_s_kernel<0, 0><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups);
 }
