@@ -184,3 +184,23 @@ def test_padded_tile_fraction_from_the_host_copy_of_the_lengths():
     assert Engine._skip_fraction(np.full(48, 925), 925) == 0.0
     t = lens_to_device(np.array([5, 3, 9], dtype=np.int64), torch.device("cpu"))
     assert t.dtype == torch.int64 and t.tolist() == [5, 3, 9] and t._fs2_host.tolist() == [5, 3, 9]
+
+
+def test_committed_pmc_traffic_file_was_measured_on_the_current_contraction_sources():
+    """bench.py's roofline.traffic comes from the newest profiles/*pmc_traffic.json (counters cannot be read inside the timed run);
+    the file records a hash of the contraction-kernel sources it was measured on and bench.py reports null on a mismatch.  This
+    test makes the mismatch visible HERE, on the CPU: a commit that edits csrc/fs2_gemm* (or fs2_sched.h) without re-running
+    tools/gpu_milestone.sh turns it red before the GPU suite's bench-contract test does."""
+    import glob
+    import json
+    import os
+    from fastspeech2_amd._lib import kernel_source_sha
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cands = sorted(glob.glob(os.path.join(root, "profiles", "*pmc_traffic.json")))
+    assert cands, "no PMC traffic file committed under profiles/"
+    doc = json.load(open(cands[-1]))
+    assert doc.get("kernel_source_sha") == kernel_source_sha(), (
+        f"{os.path.basename(cands[-1])} was measured on other contraction-kernel sources: re-run tools/gpu_milestone.sh and commit "
+        f"its *_pmc_traffic.json")
+    # and the file names the kernel the roofline line is about
+    assert any(k.startswith("conv_gemm_p_kernel<false") for k in doc["kernels"])
