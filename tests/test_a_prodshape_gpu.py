@@ -173,6 +173,52 @@ def test_tall_tile_kernel_without_lens(dev, name, Cin, Cout, k):
     assert _lib.load().fs2_conv_gemm_variant(Cin, Cout, 0, 0, 0, B * S, Cout, Cin, S, k, 1, 0, 0.0, 1) == 5
 
 
+@pytest.mark.parametrize("name,N,S,Bq", [("qkv", 768, 925, 48), ("fc", 256, 925, 48), ("w_2 dgrad", 1024, 925, 48), ("N512 short", 512, 333, 40),
+                                         ("fc 30 seqs", 256, 925, 30), ("qkv ragged tail", 768, 131, 77)])
+def test_streaming_k256_kernel_epilogues_and_edges(dev, name, N, S, Bq):
+    """conv_gemm_s_kernel (fs2_gemm_s.hip: weights in registers, X streamed through a ring of 64-row tiles behind two loader waves)
+    takes every bf16 one-tap launch with K = 256, N % 256 == 0 and at least one (tile, column group) pair per CU.  Every epilogue
+    form the engine uses through it - bias, bias + ReLU, lens (padded rows zero: the lengths are staged in LDS), residual add,
+    ReLU gate, accumulate with scale - and the edges of its schedule: row counts that are not a multiple of 64 (a last tile with
+    rows beyond M), stripes with unequal tile counts, 1 / 2 / 3 / 4 column groups (the XCD-aware 1-D grid), sequences shorter
+    than a tile.  Elementwise against the exact-product reference, rounding only; and the dispatcher really picks variant 9."""
+    ops = _ops()
+    from fastspeech2_amd import _lib
+    dtype, K = torch.bfloat16, 256
+    M = Bq * S
+    g = torch.Generator().manual_seed(sum(ord(c) for c in name) + 7)
+    assert _lib.load().fs2_conv_gemm_variant(K, N, 0, 0, 0, M, N, K, S, 1, 1, 0, 0.0, 1) == 9, "not on the streaming kernel"
+    x = torch.randn(M, K, generator=g).to(dev).to(dtype)
+    w = (torch.randn(N, 1, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    wf, _ = ops.pack_weight(w, dtype)
+    lens = torch.randint(max(1, S // 2), S + 1, (Bq,), generator=g).to(torch.int32)
+    lens[0], lens[-1] = S, max(1, S // 3)
+    lens_d = lens.to(dev)
+    ref = conv_ref_gpu(x, wf, bias, S, 0)
+    ref_nb = conv_ref_gpu(x, wf, None, S, 0)
+    assert_rounding_only(ops.conv_gemm(x, wf, bias, S), ref, dtype, (name, "bias"))
+    assert_rounding_only(ops.conv_gemm(x, wf, bias, S, act=ops.ACT_RELU), torch.relu(ref), dtype, (name, "bias + relu"))
+    y = ops.conv_gemm(x, wf, bias, S, lens=lens_d)
+    assert_rounding_only(y, conv_ref_gpu(x, wf, bias, S, 0, lens=lens), dtype, (name, "lens"))
+    pad_rows = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).reshape(-1).to(dev)
+    assert (y[pad_rows] == 0).all()
+    res = torch.randn(M, N, generator=g).to(dev).to(dtype)
+    assert_rounding_only(ops.conv_gemm(x, wf, None, S, res=res), ref_nb + res.double(), dtype, (name, "residual"))
+    assert_rounding_only(ops.conv_gemm(x, wf, None, S, act=ops.ACT_GATE, res=res, lens=lens_d),
+                         torch.where((res.double() > 0) & ~pad_rows.unsqueeze(1), ref_nb, torch.zeros_like(ref_nb)), dtype, (name, "gate + lens"))
+    acc0 = torch.randn(M, N, generator=g).to(dev).to(dtype)
+    out = acc0.clone()
+    ops.conv_gemm(x, wf, bias, S, out=out, accumulate=True, out_scale=0.5)
+    assert_rounding_only(out, acc0.double() + 0.5 * ref, dtype, (name, "accumulate"))
+    # a strided operand (the fused QKV buffer's K slice is read with ldx = 768) and a strided result
+    xs = torch.randn(M, 3 * K, generator=g).to(dev).to(dtype)
+    ys = torch.full((M, 2 * N), 7.0, device=dev, dtype=dtype)
+    ops.conv_gemm(xs[:, K:2 * K], wf, bias, S, out=ys[:, N:], ldx=3 * K, ldy=2 * N, Cin=K, N=N, M=M)
+    assert_rounding_only(ys[:, N:], conv_ref_gpu(xs[:, K:2 * K].contiguous(), wf, bias, S, 0), dtype, (name, "strided"))
+    assert (ys[:, :N] == 7.0).all()
+
+
 @pytest.mark.parametrize("name,C,N,k,dil,S,Bq", [("rb C256 k7 d3", 256, 256, 7, 3, 7200, 8), ("rb C128 k11 d5", 128, 128, 11, 5, 57600, 4),
                                                  ("rb C128 k3 d1", 128, 128, 3, 1, 57600, 4), ("rb C256 k11 d1", 256, 256, 11, 1, 7200, 8),
                                                  ("up0 as 3-tap", 512, 2048, 3, 1, 900, 8)])
