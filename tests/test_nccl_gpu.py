@@ -19,8 +19,9 @@ def test_bench_two_ranks_on_rccl(dev):
     ndev = torch.cuda.device_count()
     if ndev < 2:
         pytest.skip(f"RCCL needs one rank per GPU and this box exposes {ndev} device(s) (rocm-smi / HIP_VISIBLE_DEVICES="
-                    f"{os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}): the nccl backend has NOT been exercised here; the same exchange "
-                    f"code runs over gloo in tests/test_ddp_gpu.py (2 ranks sharing this GPU) and tests/test_ddp_gloo.py (CPU)")
+                    f"{os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}): RCCL between devices has NOT been exercised here; the same exchange "
+                    f"code runs over gloo in tests/test_ddp_gpu.py (2 ranks sharing this GPU), tests/test_ddp_gloo.py (CPU) and on a ONE-rank "
+                    f"RCCL communicator in test_one_rank_step_through_rccl_matches_plain_step below")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("FS2_BENCH_BACKEND", None)
     env.pop("FS2_BENCH_SHARE_GPU", None)
@@ -34,3 +35,70 @@ def test_bench_two_ranks_on_rccl(dev):
     assert cfg["replicas_bit_identical"] is True
     frames_per_step = d["value"] * d["ms_per_step"] * 1e-3
     assert 2 * 0.75 * 48 * 925 < frames_per_step <= 2 * 48 * 925 * 1.001
+
+
+def _one_rank_worker(port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from fastspeech2_amd import ddp
+        from fastspeech2_amd.model import FastSpeech2Loss, ScheduledOptim
+        from tests.golden import configs
+        from tests.test_ddp_gpu import _fwd_bwd, _setup
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
+        model, batch12, pcfg, mcfg = _setup(0, dev)
+        ex = ddp.GradExchange(model.flat_gradients(), 1, bucket_bytes=1 << 20)     # small buckets: many collectives under backward
+        model._engine.grad_hook = ex.ready
+        dist.broadcast(model.flat_parameters(), 0)
+        loss_fn = FastSpeech2Loss(pcfg, mcfg, count_reduce=ddp.global_counts)
+        opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
+        for i in range(2):
+            _fwd_bwd(model, batch12, loss_fn)
+            ex.finish()
+            if i == 0:
+                g1 = model.flat_gradients().clone()
+            opt.step_and_update_lr(zero_grad=True)
+        torch.cuda.synchronize()
+        q.put((dist.get_backend(), ex.n_buckets if hasattr(ex, "n_buckets") else -1, g1.cpu().numpy(),
+               model.flat_parameters().detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_step_through_rccl_matches_plain_step(dev):
+    """The exchange code on the REAL backend as far as a one-GPU box allows: `init_process_group("nccl", world_size=1)` builds an
+    RCCL communicator, and a train step then drives every piece of fastspeech2_amd/ddp.py that the 8-GPU run uses - the engine's
+    prefix hooks, the high-priority communication stream, one `all_reduce` per bucket launched UNDER backward, the hand-over
+    events before clip + Adam, the all-reduced valid counts of the loss - with RCCL kernels instead of gloo's host path.  Over one
+    rank the reduction is the identity, so two steps must reproduce the plain (no exchange) steps: gradients and parameters to
+    float-atomics noise.  What this cannot show is xGMI traffic between devices (tests/test_nccl_gpu.py::test_bench_two_ranks_on_rccl
+    needs two)."""
+    import torch.multiprocessing as mp
+    from tests.test_ddp_gpu import _free_port, _fwd_bwd, _setup
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    backend, _, g, par = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0 and backend == "nccl"
+    from fastspeech2_amd.model import FastSpeech2Loss, ScheduledOptim
+    from tests.golden import configs
+    model, b0, pcfg, mcfg = _setup(0, dev)
+    loss_fn = FastSpeech2Loss(pcfg, mcfg)
+    opt = ScheduledOptim(model, configs.TRAIN, mcfg, 0)
+    for i in range(2):
+        _fwd_bwd(model, b0, loss_fn)
+        if i == 0:
+            gref = model.flat_gradients().clone().cpu()
+        opt.step_and_update_lr(zero_grad=True)
+    torch.cuda.synchronize()
+    g, par = torch.from_numpy(g), torch.from_numpy(par)
+    assert (g - gref).abs().max().item() <= 2e-5 * gref.abs().max().item() + 1e-9
+    pref = model.flat_parameters().detach().cpu()
+    assert (par - pref).abs().max().item() <= 1e-5 * pref.abs().max().item()
