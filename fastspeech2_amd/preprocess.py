@@ -162,13 +162,11 @@ class RunningMoments:
 
 
 def remove_outlier(values):
-    """preprocessor.py:283-291: keep values strictly inside [p25 - 1.5 IQR, p75 + 1.5 IQR]."""
-    values = np.array(values)
-    p25 = np.percentile(values, 25)
-    p75 = np.percentile(values, 75)
-    lower = p25 - 1.5 * (p75 - p25)
-    upper = p75 + 1.5 * (p75 - p25)
-    return values[np.logical_and(values > lower, values < upper)]
+    """preprocessor.py:283-291: Tukey fence - keep what lies strictly inside (Q1 - 1.5 IQR, Q3 + 1.5 IQR)."""
+    v = np.asarray(values)
+    q1, q3 = np.percentile(v, [25, 75])
+    fence = 1.5 * (q3 - q1)
+    return v[(v > q1 - fence) & (v < q3 + fence)]
 
 
 def phoneme_average(values, durations):
@@ -325,16 +323,16 @@ class Preprocessor:
                 mel_spectrogram.shape[1])
 
     def normalize(self, in_dir, mean, std):
-        """preprocessor.py:293-305: rewrite every file as (x - mean) / std, return the corpus (min, max)."""
-        max_value = np.finfo(np.float64).min
-        min_value = np.finfo(np.float64).max
-        for filename in os.listdir(in_dir):
-            filename = os.path.join(in_dir, filename)
-            values = (np.load(filename) - mean) / std
-            np.save(filename, values)
-            max_value = max(max_value, max(values))
-            min_value = min(min_value, min(values))
-        return min_value, max_value
+        """preprocessor.py:293-305: standardise every .npy of `in_dir` in place; returns the (min, max) over the whole corpus
+        (float64 extremes when the directory is empty, as the reference's running min / max start there)."""
+        lo, hi = np.finfo(np.float64).max, np.finfo(np.float64).min
+        for name in os.listdir(in_dir):
+            path = os.path.join(in_dir, name)
+            z = (np.load(path) - mean) / std
+            np.save(path, z)
+            if z.size:
+                lo, hi = min(lo, z.min()), max(hi, z.max())
+        return lo, hi
 
     # ---------------------------------------------------------------- the corpus pass
     def build_from_path(self):
