@@ -44,18 +44,27 @@ __device__ __forceinline__ void s_barrier_mem() {
 // loaded value once stores are pending too - loads and stores can retire out of order - so every tile would pay the store latency:
 // the first cut of this epilogue ran 5 us per 64-row tile, waves parked 66 %, r04v_s_pmc_mfma.md): the bias line sits in registers
 // (bb), the lengths in LDS (lens_s), and the residual / gate operand of THIS tile (rr) was requested before the tile's MFMAs.
-template <int ACT, int ABL>
+//
+// EPI: what the epilogue has to do, decided by the LAUNCHER and compiled in - bit 0 residual add, bit 1 ReLU gate on the residual
+// operand, bit 2 lengths (padded rows zero), bit 3 "anything" (accumulate / out_scale != 1: every feature behind run-time flags, the
+// first cut's form).  A wave issues about one instruction per 5 cycles and the run-time-flag form is 12 VALU per output element
+// (selects for flags that are off, a multiply by 1.0, the unpacking of a residual that is not there): the epilogue, not the MFMAs or
+// the stream, was the longest phase of a tile (r04x_s_abl.log).  Compiled for what the launch needs it is 3-6.
+enum { S_EPI_RES = 1, S_EPI_GATE = 2, S_EPI_LENS = 4, S_EPI_ANY = 8 };
+template <int ACT, int ABL, int EPI>
 __device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][1], int m0, int nbase, int fl, int fh,
                                            const float* bias_s, const int32_t* lens_s, const uint4 (&rr)[2][2]) {
+    constexpr bool ANY = (EPI & S_EPI_ANY) != 0;
     bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
-    const bool has_r = a.R != nullptr;
-    const bool gate = a.act == FS2_ACT_GATE;
+    const bool has_r = ANY ? a.R != nullptr : (EPI & (S_EPI_RES | S_EPI_GATE)) != 0;
+    const bool gate = ANY ? a.act == FS2_ACT_GATE : (EPI & S_EPI_GATE) != 0;
+    const bool has_lens = ANY ? a.lens != nullptr : (EPI & S_EPI_LENS) != 0;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int m = m0 + mb * 32 + fl;
         const bool rowok = m < a.M;
         bool padrow = false;
-        if (a.lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
+        if (has_lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
         bf16_t* yrow = Y + (size_t)m * a.ldy;
 #pragma unroll
         for (int nb = 0; nb < 1; ++nb) {
@@ -83,9 +92,15 @@ __device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
                         v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
                     }
                 }
+                if (ANY) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] *= a.out_scale; if (padrow) v[e] = 0.f; }
-                if (a.accumulate) {
+                    for (int e = 0; e < 8; ++e) v[e] *= a.out_scale;
+                }
+                if (has_lens) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (padrow) v[e] = 0.f;
+                }
+                if (ANY && a.accumulate) {
                     const uint4 yy = *reinterpret_cast<const uint4*>(yrow + n);
                     const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy);
 #pragma unroll
@@ -107,7 +122,7 @@ __device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
 // wave's MFMAs overlap the other's epilogue VALU work (the barrier per tile otherwise keeps all waves in the same phase).  Measured
 // (r04x_s_skew.log; wave i sits on SIMD {3,0,2,1}[i % 4], so waves w and w + 4 do share one): no gain from any pairing - the kernel
 // is bound by bytes moved per CU, not by issue slots - so the product launches SKEW = 0 and the modes stay a dev switch.
-template <int ABL, int SKEW>
+template <int ABL, int SKEW, int EPI>
 __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, int ntiles, int stripes, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -183,7 +198,7 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
     const bf16_t* Rb = reinterpret_cast<const bf16_t*>(a.R);
     const unsigned arow = (unsigned)(fl * 512);              // byte offset of the lane's row (second row block: + 32 rows)
     unsigned akey = (unsigned)(fl & 15);
-    const bool late = SKEW == 1 ? wave >= 4 : SKEW == 2 ? (wave & 1) != 0 : SKEW == 3 ? ((wave >> 1) & 1) != 0 : false;
+    const bool late = SKEW == 1 && wave >= 4;
     f32x16 acc[2][1];
     uint4 rr[2][2];
     int m0 = 0;
@@ -195,7 +210,13 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
                 for (int r_ = 0; r_ < 16; ++r_) sink += acc[i_][0][r_];                                                         \
             if (sink == 123.456f) reinterpret_cast<float*>(a.Y)[0] = sink;                                                      \
         } else {                                                                                                                \
-            FS2_ACT_DISPATCH(a.act, (s_epilogue<ACT, ABL>(a, acc, m0, nbase, fl, fh, bias_s, lens_s, rr)));                     \
+            if (EPI & S_EPI_ANY) {                                                                                              \
+                FS2_ACT_DISPATCH(a.act, (s_epilogue<ACT, ABL, EPI>(a, acc, m0, nbase, fl, fh, bias_s, lens_s, rr)));                 \
+            } else if (a.act == FS2_ACT_RELU) { /* (tanh / leaky ReLU launches take the S_EPI_ANY kernel) */                    \
+                s_epilogue<FS2_ACT_RELU, ABL, EPI>(a, acc, m0, nbase, fl, fh, bias_s, lens_s, rr);                                  \
+            } else {                                                                                                            \
+                s_epilogue<FS2_ACT_NONE, ABL, EPI>(a, acc, m0, nbase, fl, fh, bias_s, lens_s, rr);                                  \
+            }                                                                                                                   \
         }                                                                                                                       \
     } while (0)
     for (int t = 0; t < my_tiles; ++t) {
@@ -212,7 +233,8 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
             const int m = min(m0 + mb * 32 + fl, a.M - 1);
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
-                rr[mb][ch] = Rb ? *reinterpret_cast<const uint4*>(Rb + (size_t)m * a.ldr + nbase + ch * 16 + fh * 8) : make_uint4(0, 0, 0, 0);
+                rr[mb][ch] = ((EPI & S_EPI_ANY) ? Rb != nullptr : (EPI & (S_EPI_RES | S_EPI_GATE)) != 0)
+                                 ? *reinterpret_cast<const uint4*>(Rb + (size_t)m * a.ldr + nbase + ch * 16 + fh * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -260,20 +282,14 @@ bool fs2_conv_gemm_s_ok(const ConvGemmArgs& a, int dtype) {
     return (long)fs2_cdiv(a.M, S_TM) * (a.N / 256) >= s_cu_count();
 }
 
-void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream) {
+template <int ABL, int SKEW, int EPI>
+static void s_launch_one(const ConvGemmArgs& a, dim3 grid, int ntiles, int stripes, int groups, hipStream_t stream) {
     static Fs2DevOnce once;
-    once.run([&] {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-#ifdef FS2_DEV
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
-#endif
-    });
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<ABL, SKEW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS); });
+    conv_gemm_s_kernel<ABL, SKEW, EPI><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups);
+}
+
+void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream) {
     const int ntiles = fs2_cdiv(a.M, S_TM), groups = a.N / 256;
     // one workgroup per CU (133 KB of LDS); with several column groups the stripe count is a multiple of 8 (see the kernel's map)
     int stripes = s_cu_count() / groups;
@@ -282,14 +298,26 @@ void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream) {
     if (stripes < 8) { stripes = 8; }                        // (tiles past ntiles: a stripe with no tile returns at once)
     const dim3 grid((unsigned)(stripes * groups));
 #ifdef FS2_DEV
-    static const int abl = fs2_dev_env("FS2_S_ABL", 0), skew = fs2_dev_env("FS2_S_SKEW", 0);
-    if (skew == 1) { conv_gemm_s_kernel<0, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
-    if (skew == 2) { conv_gemm_s_kernel<0, 2><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
-    if (skew == 3) { conv_gemm_s_kernel<0, 3><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
-    if (abl == 1) { conv_gemm_s_kernel<1, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
-    if (abl == 2) { conv_gemm_s_kernel<2, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
-    if (abl == 3) { conv_gemm_s_kernel<3, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
-    if (abl == 4) { conv_gemm_s_kernel<4, 1><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups); return; }
+    static const int abl = fs2_dev_env("FS2_S_ABL", 0), skew = fs2_dev_env("FS2_S_SKEW", 0), any = fs2_dev_env("FS2_S_EPI_ANY", 0);
+    if (skew == 1) { s_launch_one<0, 1, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); return; }
+    if (abl == 1) { s_launch_one<1, 0, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); return; }
+    if (abl == 2) { s_launch_one<2, 0, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); return; }
+    if (abl == 3) { s_launch_one<3, 0, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); return; }
+    if (abl == 4) { s_launch_one<4, 0, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); return; }
+    if (any) { s_launch_one<0, 0, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); return; }
 #endif
-    conv_gemm_s_kernel<0, 0><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups);
+    // the epilogue this launch needs (see s_epilogue): accumulate / a scale fall back to the run-time-flag form
+    const bool gate = a.act == FS2_ACT_GATE;
+    const bool odd_act = a.act == FS2_ACT_TANH || a.act == FS2_ACT_LRELU;
+    int epi = (a.accumulate || a.out_scale != 1.0f || (gate && !a.R) || odd_act) ? S_EPI_ANY
+              : ((a.R ? (gate ? S_EPI_GATE : S_EPI_RES) : 0) | (a.lens ? S_EPI_LENS : 0));
+    switch (epi) {
+        case 0: s_launch_one<0, 0, 0>(a, grid, ntiles, stripes, groups, stream); break;
+        case S_EPI_RES: s_launch_one<0, 0, S_EPI_RES>(a, grid, ntiles, stripes, groups, stream); break;
+        case S_EPI_GATE: s_launch_one<0, 0, S_EPI_GATE>(a, grid, ntiles, stripes, groups, stream); break;
+        case S_EPI_LENS: s_launch_one<0, 0, S_EPI_LENS>(a, grid, ntiles, stripes, groups, stream); break;
+        case S_EPI_RES | S_EPI_LENS: s_launch_one<0, 0, S_EPI_RES | S_EPI_LENS>(a, grid, ntiles, stripes, groups, stream); break;
+        case S_EPI_GATE | S_EPI_LENS: s_launch_one<0, 0, S_EPI_GATE | S_EPI_LENS>(a, grid, ntiles, stripes, groups, stream); break;
+        default: s_launch_one<0, 0, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); break;
+    }
 }
