@@ -24,6 +24,17 @@ struct ConvGemmArgs {
     int dbg;                       // dev ablations (FS2_GEMM_DBG): 1 = loaders issue no DMA, 2 = consumers issue no MFMA
 };
 
+// gemm_res_ln (N == 256: a workgroup owns whole rows): the epilogue of the projection IS the LayerNorm kernel
+//   z = dropout(acc + bias) + res  (stored bf16 into Y: saved for backward)    out = mask(LN(z) * gamma + beta)    mean / rstd saved
+struct WLn {
+    const float* gamma; const float* beta;   // gamma == null: plain contraction
+    void* out; long ldo;
+    float* mean; float* rstd;
+    float eps, p_pre;
+    uint64_t seed_pre;
+    const uint64_t* seed_dev;
+};
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     switch (act) {
         case FS2_ACT_RELU: return fmaxf(v, 0.f);

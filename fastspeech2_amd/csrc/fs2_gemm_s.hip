@@ -27,7 +27,8 @@
 static constexpr int S_TM = 64, S_K = 256, S_NBUF = 4;
 static constexpr int S_TILE_BYTES = S_TM * S_K * 2;      // 32 KB
 static constexpr int S_MAXB = 1024;                      // lens[] staged in LDS
-static constexpr int S_LDS = S_NBUF * S_TILE_BYTES + S_MAXB * 4 + 256 * 4;      // 133 KB (+ the lengths, + the workgroup's bias line)
+static constexpr int S_AUX = S_MAXB * 4 + 3 * 256 * 4 + 2 * 8 * 64 * 4;               // lengths, bias / gamma / beta lines, row-sum exchange
+static constexpr int S_LDS = S_NBUF * S_TILE_BYTES + S_AUX;                           // 139 KB
 static constexpr int S_NLOAD = 2;                        // loader waves
 static constexpr int S_CONS = 8;                         // consumer waves (32 output columns each)
 static constexpr int S_THREADS = (S_CONS + S_NLOAD) * 64;
@@ -50,7 +51,120 @@ __device__ __forceinline__ void s_barrier_mem() {
 // first cut's form).  A wave issues about one instruction per 5 cycles and the run-time-flag form is 12 VALU per output element
 // (selects for flags that are off, a multiply by 1.0, the unpacking of a residual that is not there): the epilogue, not the MFMAs or
 // the stream, was the longest phase of a tile (r04x_s_abl.log).  Compiled for what the launch needs it is 3-6.
-enum { S_EPI_RES = 1, S_EPI_GATE = 2, S_EPI_LENS = 4, S_EPI_ANY = 8 };
+enum { S_EPI_RES = 1, S_EPI_GATE = 2, S_EPI_LENS = 4, S_EPI_ANY = 8, S_EPI_LN = 16 };
+// gemm_res_ln on this kernel (EPI = S_EPI_LN; N = 256, so the workgroup's eight waves hold whole rows): the epilogue of fs2_gemm_w.hip's
+// w_epilogue_resln in this kernel's layout - z = dropout(acc + bias) + res stored bf16 (saved for backward), statistics on the values
+// AS STORED, two passes (mean, then squared deviations), each row's eight per-wave partial sums exchanged through LDS behind one
+// barrier per pass (the loader waves pass the same barriers), out = mask(LN(z) gamma + beta), mean / rstd saved.
+// transformer/SubLayers.py:54-55 + Layers.py:25 (fc -> dropout -> + residual -> LayerNorm -> masked_fill).
+__device__ __forceinline__ void s_epilogue_ln(const ConvGemmArgs& a, const WLn& ln, f32x16 (&acc)[2][1], int m0, int nbase, int wave, int fl, int fh,
+                                              const float* bias_s, const float* gamma_s, const float* beta_s, const int32_t* lens_s,
+                                              const uint4 (&rr)[2][2], float* red, uint64_t seed, float ik) {
+    bf16_t* Z = reinterpret_cast<bf16_t*>(a.Y);
+    bf16_t* O = reinterpret_cast<bf16_t*>(ln.out);
+    float rsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + mb * 32 + fl;
+        const bool rowok = m < a.M;
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][0][e]), __float_as_uint(acc[mb][0][4 + e]), false, false);
+            u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][0][8 + e]), __float_as_uint(acc[mb][0][12 + e]), false, false);
+            v[e] = __uint_as_float(s0[0]); v[4 + e] = __uint_as_float(s0[1]);
+            v[8 + e] = __uint_as_float(s1[0]); v[12 + e] = __uint_as_float(s1[1]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int n = nbase + ch * 16 + fh * 8;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = v[ch * 8 + e] + bias_s[ch * 8 + e];
+            if (ln.p_pre > 0.f) {
+                const uint32_t e0 = (uint32_t)m * 256u + (uint32_t)n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] *= fs2_drop_scale(seed, e0 + e, ln.p_pre, ik);
+            }
+            if (a.R) {
+                const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr[mb][ch]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[2 * e] += __uint_as_float(u[e] << 16); x[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+            }
+            uint4 zq;
+            uint32_t* zu = reinterpret_cast<uint32_t*>(&zq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zu[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
+            if (rowok) *reinterpret_cast<uint4*>(Z + (size_t)m * a.ldy + n) = zq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                // statistics on the values as stored: backward sees the same z
+                const float lo = __uint_as_float(zu[e] << 16), hi = __uint_as_float(zu[e] & 0xffff0000u);
+                acc[mb][0][ch * 8 + 2 * e] = lo; acc[mb][0][ch * 8 + 2 * e + 1] = hi;
+                rsum[mb] += lo + hi;
+            }
+        }
+    }
+    // ---- row means: lane pair, then the eight waves through LDS
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        rsum[mb] += __shfl_xor(rsum[mb], 32, 64);
+        if (fh == 0) red[wave * 64 + mb * 32 + fl] = rsum[mb];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[w * 64 + mb * 32 + fl];         // (same order in every wave: one mean per row)
+        mean[mb] = t * (1.f / 256.f);
+    }
+    float rsq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[mb][0][r] - mean[mb]; rsq[mb] += d * d; }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        rsq[mb] += __shfl_xor(rsq[mb], 32, 64);
+        if (fh == 0) red[512 + wave * 64 + mb * 32 + fl] = rsq[mb];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[512 + w * 64 + mb * 32 + fl];
+        rstd[mb] = rsqrtf(t * (1.f / 256.f) + ln.eps);
+    }
+    // ---- normalise, scale, mask, store
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + mb * 32 + fl;
+        if (m >= a.M) continue;
+        bool padrow = false;
+        if (a.lens) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
+        if (wave == 0 && fh == 0) { ln.mean[m] = mean[mb]; ln.rstd[m] = rstd[mb]; }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int n = nbase + ch * 16 + fh * 8;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = padrow ? 0.f : (acc[mb][0][ch * 8 + e] - mean[mb]) * rstd[mb] * gamma_s[ch * 8 + e] + beta_s[ch * 8 + e];
+            uint4 oq;
+            uint32_t* ou = reinterpret_cast<uint32_t*>(&oq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+            *reinterpret_cast<uint4*>(O + (size_t)m * ln.ldo + n) = oq;
+        }
+    }
+}
+
 template <int ACT, int ABL, int EPI>
 __device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][1], int m0, int nbase, int fl, int fh,
                                            const float* bias_s, const int32_t* lens_s, const uint4 (&rr)[2][2]) {
@@ -123,7 +237,7 @@ __device__ __forceinline__ void s_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
 // (r04x_s_skew.log; wave i sits on SIMD {3,0,2,1}[i % 4], so waves w and w + 4 do share one): no gain from any pairing - the kernel
 // is bound by bytes moved per CU, not by issue slots - so the product launches SKEW = 0 and the modes stay a dev switch.
 template <int ABL, int SKEW, int EPI>
-__global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, int ntiles, int stripes, int groups) {
+__global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, WLn ln, int ntiles, int stripes, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,6 +281,7 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
             else s_wait_vm<0>();
             s_barrier_mem();                                 // tile t published; the buffer of tile t - 1 released
             if (t + 3 < my_tiles) issue(t + 3);
+            if (EPI & S_EPI_LN) { s_barrier_mem(); s_barrier_mem(); }        // (the consumers' two row-sum exchanges)
         }
         return;
     }
@@ -185,9 +300,14 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
     // bias layout: [wave][half][run][8] so that a lane reads its two 8-column runs as 16 consecutive floats
     int32_t* lens_s = reinterpret_cast<int32_t*>(smem + S_NBUF * S_TILE_BYTES);
     float* bias_all = reinterpret_cast<float*>(smem + S_NBUF * S_TILE_BYTES + S_MAXB * 4);
+    float* gamma_all = bias_all + 256;
+    float* beta_all = bias_all + 512;
+    float* red = bias_all + 768;                             // [2][8 waves][64 rows]
     if (tid < 256) {
         const int w_ = tid >> 5, r_ = tid & 31, ch_ = r_ >> 4, fh_ = (r_ >> 3) & 1, e_ = r_ & 7;
-        bias_all[w_ * 32 + fh_ * 16 + ch_ * 8 + e_] = a.bias ? a.bias[col_group * 256 + tid] : 0.f;
+        const int slot = w_ * 32 + fh_ * 16 + ch_ * 8 + e_;
+        bias_all[slot] = a.bias ? a.bias[col_group * 256 + tid] : 0.f;
+        if (EPI & S_EPI_LN) { gamma_all[slot] = ln.gamma[tid]; beta_all[slot] = ln.beta[tid]; }
     }
     if (a.lens) {
         const int Bq = a.M / a.S;
@@ -195,6 +315,10 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const float* bias_s = bias_all + wave * 32 + fh * 16;
+    const float* gamma_s = gamma_all + wave * 32 + fh * 16;
+    const float* beta_s = beta_all + wave * 32 + fh * 16;
+    const uint64_t ln_seed = (EPI & S_EPI_LN) ? ln.seed_pre + (ln.seed_dev ? *ln.seed_dev : 0ull) : 0ull;
+    const float ln_ik = ((EPI & S_EPI_LN) && ln.p_pre > 0.f) ? 1.f / (1.f - ln.p_pre) : 1.f;
     const bf16_t* Rb = reinterpret_cast<const bf16_t*>(a.R);
     const unsigned arow = (unsigned)(fl * 512);              // byte offset of the lane's row (second row block: + 32 rows)
     unsigned akey = (unsigned)(fl & 15);
@@ -209,6 +333,8 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
             for (int i_ = 0; i_ < 2; ++i_)                                                                                      \
                 for (int r_ = 0; r_ < 16; ++r_) sink += acc[i_][0][r_];                                                         \
             if (sink == 123.456f) reinterpret_cast<float*>(a.Y)[0] = sink;                                                      \
+        } else if (EPI & S_EPI_LN) {                                                                                            \
+            s_epilogue_ln(a, ln, acc, m0, nbase, wave, fl, fh, bias_s, gamma_s, beta_s, lens_s, rr, red, ln_seed, ln_ik);              \
         } else {                                                                                                                \
             if (EPI & S_EPI_ANY) {                                                                                              \
                 FS2_ACT_DISPATCH(a.act, (s_epilogue<ACT, ABL, EPI>(a, acc, m0, nbase, fl, fh, bias_s, lens_s, rr)));                 \
@@ -233,7 +359,7 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
             const int m = min(m0 + mb * 32 + fl, a.M - 1);
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
-                rr[mb][ch] = ((EPI & S_EPI_ANY) ? Rb != nullptr : (EPI & (S_EPI_RES | S_EPI_GATE)) != 0)
+                rr[mb][ch] = ((EPI & (S_EPI_ANY | S_EPI_LN)) ? Rb != nullptr : (EPI & (S_EPI_RES | S_EPI_GATE)) != 0)
                                  ? *reinterpret_cast<const uint4*>(Rb + (size_t)m * a.ldr + nbase + ch * 16 + fh * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
@@ -283,10 +409,10 @@ bool fs2_conv_gemm_s_ok(const ConvGemmArgs& a, int dtype) {
 }
 
 template <int ABL, int SKEW, int EPI>
-static void s_launch_one(const ConvGemmArgs& a, dim3 grid, int ntiles, int stripes, int groups, hipStream_t stream) {
+static void s_launch_one(const ConvGemmArgs& a, dim3 grid, int ntiles, int stripes, int groups, hipStream_t stream, const WLn& ln = WLn{}) {
     static Fs2DevOnce once;
     once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_s_kernel<ABL, SKEW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS); });
-    conv_gemm_s_kernel<ABL, SKEW, EPI><<<grid, S_THREADS, S_LDS, stream>>>(a, ntiles, stripes, groups);
+    conv_gemm_s_kernel<ABL, SKEW, EPI><<<grid, S_THREADS, S_LDS, stream>>>(a, ln, ntiles, stripes, groups);
 }
 
 void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream) {
@@ -320,4 +446,16 @@ void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream) {
         case S_EPI_GATE | S_EPI_LENS: s_launch_one<0, 0, S_EPI_GATE | S_EPI_LENS>(a, grid, ntiles, stripes, groups, stream); break;
         default: s_launch_one<0, 0, S_EPI_ANY>(a, grid, ntiles, stripes, groups, stream); break;
     }
+}
+
+// ---- gemm_res_ln on the streaming kernel (called by fs2_gemm_res_ln_fwd, fs2_gemm_w.hip)
+bool fs2_conv_gemm_s_ln_ok(const ConvGemmArgs& a, int dtype) {
+    return a.N == 256 && a.act == FS2_ACT_NONE && !a.accumulate && a.out_scale == 1.0f && fs2_conv_gemm_s_ok(a, dtype);
+}
+
+void fs2_conv_gemm_s_ln_launch(const ConvGemmArgs& a, const WLn& ln, hipStream_t stream) {
+    const int ntiles = fs2_cdiv(a.M, S_TM);
+    int stripes = s_cu_count();
+    if (stripes > ntiles) stripes = ntiles;
+    s_launch_one<0, 0, S_EPI_LN>(a, dim3((unsigned)stripes), ntiles, stripes, 1, stream, ln);
 }

@@ -41,14 +41,7 @@ struct WPos { int k, s, mt, nt; };                       // k-th unit of this wo
 //   z = dropout(acc + bias) + res  (stored bf16 into Y: saved for backward)    out = mask(LN(z) * gamma + beta)    mean / rstd saved
 // == fs2_conv_gemm followed by fs2_ln_fwd (transformer/SubLayers.py:54-55, 90-93 + Layers.py:25,28) without the projection's
 // output making a round trip through HBM (one bf16 rounding less: y is never stored) and without the second launch.
-struct WLn {
-    const float* gamma; const float* beta;   // gamma == null: plain contraction
-    void* out; long ldo;
-    float* mean; float* rstd;
-    float eps, p_pre;
-    uint64_t seed_pre;
-    const uint64_t* seed_dev;
-};
+// (struct WLn: fs2_gemm.h - shared with the streaming kernel's LayerNorm epilogue)
 
 // Layout after the half-wave swaps: lane (fl, fh) of wave (wm, wn) holds, for its two rows m = m0 + 64 wm + 32 mb + fl, the
 // columns 128 wn + 32 nb + 16 ch + 8 fh + [0, 8) as v[mb][nb][8 ch + e].  A row is spread over the lane pair (fh = 0, 1) and the
@@ -373,11 +366,26 @@ void fs2_conv_gemm_w_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
     w_launch(a, tile_map, ln, stream);
 }
 
+// defined in fs2_gemm_s.hip
+bool fs2_conv_gemm_s_ln_ok(const ConvGemmArgs& a, int dtype);
+void fs2_conv_gemm_s_ln_launch(const ConvGemmArgs& a, const WLn& ln, hipStream_t stream);
+
 // ---- gemm_res_ln: Linear (N = 256) + dropout + residual + LayerNorm + pad-row zero in one launch (SURVEY §8(b) export list)
 extern "C" int fs2_gemm_res_ln_supported(int M, int N, int Cin, int S, int dtype) {
     if (dtype != FS2_BF16 || N != 256 || Cin % 32 != 0 || Cin < 128 || M <= 0 || S <= 0 || M % S != 0) return 0;
     if ((double)M * Cin * 2 >= 4.0e9 || M / S > W_MAXB) return 0;
     return fs2_cdiv(M, 256) >= 16 ? 1 : 0;                // fewer tiles: the separate small-tile kernels keep more CUs busy
+}
+
+// 1 when fs2_gemm_res_ln_fwd would run this shape on the streaming K = 256 kernel (fs2_gemm_s.hip) - the form that is FASTER than
+// the two launches at the train step's decoder shapes; 0: the wide-tile form (or unsupported).  A flag, not a status.
+extern "C" int fs2_gemm_res_ln_streams(int M, int N, int Cin, int S, int dtype) {
+    if (!fs2_gemm_res_ln_supported(M, N, Cin, S, dtype)) return 0;
+    ConvGemmArgs a = {};
+    a.ldx = Cin; a.ldw = Cin; a.ldy = N; a.ldr = N; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = 1; a.dil = 1; a.act = FS2_ACT_NONE;
+    a.in_act = FS2_ACT_NONE; a.out_scale = 1.f; a.vec_ok = 1;
+    a.lens = reinterpret_cast<const int32_t*>(1);          // (a launch with lens: the batch-size bound of the LDS lengths table applies)
+    return fs2_conv_gemm_s_ln_ok(a, dtype) ? 1 : 0;
 }
 
 extern "C" int fs2_gemm_res_ln_fwd(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Z, long ldz,
@@ -396,7 +404,9 @@ extern "C" int fs2_gemm_res_ln_fwd(const void* X, long ldx, const void* Wpacked,
     WLn ln;
     ln.gamma = gamma; ln.beta = beta; ln.out = out; ln.ldo = ldo; ln.mean = mean; ln.rstd = rstd; ln.eps = eps; ln.p_pre = p_pre;
     ln.seed_pre = seed_pre; ln.seed_dev = seed_dev;
-    w_launch(a, tile_map, ln, stream);
+    // K = 256 with enough 64-row tiles to give every CU one: the streaming kernel (weights in registers) with the same epilogue
+    if (fs2_conv_gemm_s_ln_ok(a, dtype)) fs2_conv_gemm_s_ln_launch(a, ln, stream);
+    else w_launch(a, tile_map, ln, stream);
     FS2_CHECK_LAUNCH("gemm_res_ln");
     return FS2_OK;
 }

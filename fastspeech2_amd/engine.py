@@ -85,7 +85,7 @@ class Engine:
         # the device tensors (`_fs2_host`, lost by .to() / clone / slicing, stale when a static buffer is refilled with copy_)
         self.length_hint = None
         self._wgrad_ws = ops.WgradWorkspaces()      # split-K scratch of the weight gradients: lives and dies with this engine
-        self.fuse_proj_ln = False       # see _proj_ln: the one-launch form is measured slower at the bench shape
+        self.fuse_proj_ln = False       # see _proj_ln: True = every N = 256 projection, "stream" = only where the streaming kernel runs it
         self._pack_pending = False
         self._bn_ws = {}
         self._bn_eval = {}
@@ -318,15 +318,19 @@ class Engine:
 
     def _proj_ln(self, W, key, x, res, ln, lens, B, S, p, site, seed_dev):
         """N = 256 projection -> dropout -> + residual -> LayerNorm.  Returns (z, out, mean, rstd) with z = what ln_bwd needs.
-        `fuse_proj_ln` runs it as ONE launch (fs2_gemm_res_ln_fwd: the pre-norm tensor makes one HBM trip instead of three);
-        measured on the step it is SLOWER than the two launches (8.90 vs 8.68 ms, profiles/r03k_ab_env.log, r03l_ab_env.log:
-        the 256-row x full-width tile leaves 174 workgroups for 256 CUs and the row statistics serialise the epilogue), so the
-        default stays two launches; the fused operator stays in the library, parity-tested, for shapes with more rows."""
+        `fuse_proj_ln` runs it as ONE launch (fs2_gemm_res_ln_fwd: the pre-norm tensor makes one HBM trip instead of three).
+        True = every projection: on the wide-tile kernel that is SLOWER than two launches (8.90 vs 8.68 ms per step,
+        profiles/r03k_ab_env.log, r03l_ab_env.log: 174 workgroups for 256 CUs).  "stream" = only where the streaming K = 256 kernel
+        runs it (the attention sub-layer's fc at the decoder's row count): faster in isolation (27.4 vs 33.9 us without dropout,
+        33.9 vs 37.6 us with p = 0.2: the per-element dropout hash sits in an epilogue nothing overlaps) and step-neutral (8.35 vs
+        8.37 ms, profiles/r04z_ab_fuse_ln.log), so the default stays two launches - no change of the step's rounding pattern
+        for nothing."""
         gamma, beta = self.P[ln + "weight"], self.P[ln + "bias"]
         kw = _seed_kw("seed_pre", site, seed_dev)
         if self.fuse_proj_ln and lens is not None:
             wf, _, b, _ = W[key]
-            r = ops.gemm_res_ln(x, wf, b, res, gamma, beta, lens, self._tmap(lens), B, S, p_pre=p, **kw)
+            r = ops.gemm_res_ln(x, wf, b, res, gamma, beta, lens, self._tmap(lens), B, S, p_pre=p,
+                                streaming_only=self.fuse_proj_ln == "stream", **kw)
             if r is not None:
                 return r
         y = self._gemm(W, key, x, S, lens=lens)

@@ -269,13 +269,16 @@ def ln_fwd(y, res, gamma, beta, lens, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, p_p
     return out, mean, rstd
 
 
-def gemm_res_ln(x, wpacked, bias, res, gamma, beta, lens, tmap, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, seed_dev=None):
+def gemm_res_ln(x, wpacked, bias, res, gamma, beta, lens, tmap, B, S, eps=1e-5, p_pre=0.0, seed_pre=0, seed_dev=None, streaming_only=False):
     """Linear (N = 256) + dropout + residual + LayerNorm + pad-row zero in ONE launch (fs2_gemm_res_ln_fwd).  Returns
     (z, out, mean, rstd) exactly like conv_gemm followed by ln_fwd (z is what ln_fwd leaves in its y argument), or None when the
     shape is not supported (the caller then runs the two launches)."""
     M, Cin = x.shape
     N = wpacked.shape[0]
     if x.dtype != torch.bfloat16 or wpacked.shape[1] != 1 or not _lib.load().fs2_gemm_res_ln_supported(M, N, Cin, S, BF16):
+        return None
+    streams = bool(_lib.load().fs2_gemm_res_ln_streams(M, N, Cin, S, BF16))
+    if streaming_only and not streams:                   # (the wide-tile form is slower than two launches at the step's shapes)
         return None
     z = torch.empty(M, N, device=x.device, dtype=x.dtype)
     out = torch.empty(M, N, device=x.device, dtype=x.dtype)
@@ -289,7 +292,7 @@ def gemm_res_ln(x, wpacked, bias, res, gamma, beta, lens, tmap, B, S, eps=1e-5, 
               _stream())
     if PROFILE is not None:
         e1.record()
-        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin, e0, e1, 7, lens is not None, S))
+        PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin, e0, e1, 9 if streams else 7, lens is not None, S))
     return z, out, mean, rstd
 
 

@@ -143,6 +143,8 @@ int fs2_ln_fwd(void* y, const void* res, const float* gamma, const float* beta, 
  * projection's output is never stored (one bf16 rounding less).  bf16, N == 256, Cin % 32 == 0; fs2_gemm_res_ln_supported
  * returns 1 / 0 (a flag, not a status) - otherwise call the two entry points. */
 int fs2_gemm_res_ln_supported(int M, int N, int Cin, int S, int dtype);
+/* 1 when the shape runs on the streaming K = 256 kernel (weights in registers, 64-row tiles: every CU busy at the decoder's M) */
+int fs2_gemm_res_ln_streams(int M, int N, int Cin, int S, int dtype);
 int fs2_gemm_res_ln_fwd(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Z, long ldz,
                         void* out, long ldo, const float* gamma, const float* beta, float* mean, float* rstd, const int32_t* lens,
                         const int32_t* tile_map, int M, int N, int Cin, int S, float eps, float p_pre, uint64_t seed_pre,

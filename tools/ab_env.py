@@ -24,6 +24,8 @@ def one():
         ops.conv_wgrad = lambda *a, **k: None
     if os.environ.get("AB_FUSE_LN") == "1":
         model._engine.fuse_proj_ln = True
+    if os.environ.get("AB_FUSE_LN") == "stream":
+        model._engine.fuse_proj_ln = "stream"
     if os.environ.get("AB_WGRAD_LATE") == "0":
         model._engine.wgrad_after_dgrad = False
     if os.environ.get("AB_LENS_FWD") in ("0", "1"):          # FFT-block contractions with / without lens (default: without)
