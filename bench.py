@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py — mel-frames/s of the FastSpeech 2 TRAIN step on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W            (N>1: under torch.distributed.run, or bare - it then re-executes
+                                                              itself under torch.distributed.run with N ranks)
 
 A "step" = forward + FastSpeech2Loss + backward + (RCCL gradient all-reduce) + global-norm clip + Adam over one
 synthetic LJSpeech-shaped batch per GPU (config 2 of BASELINE.json: 4+4 FFT layers, d=256, 2 heads, 80-bin mel,
@@ -441,6 +442,28 @@ def synth_main(args):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started WITHOUT a launcher (the way the driver starts N = 1): re-execute this command line
+    under `python -m torch.distributed.run` with N ranks on this node - exactly the launch the task contract names - and pass
+    rank 0's JSON line through.  The torchrun form itself (WORLD_SIZE already set) never comes here."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n and os.environ.get("FS2_BENCH_SHARE_GPU") != "1":
+        print(f"bench.py --gpus {n}: this node exposes {ndev} GPU(s); one rank per GPU needs {n} (FS2_BENCH_SHARE_GPU=1 + "
+              f"FS2_BENCH_BACKEND=gloo put the ranks on one device for a functional check only)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if os.environ.get("FS2_BENCH_SHARE_GPU") == "1":
+        env.setdefault("FS2_BENCH_BACKEND", "gloo")           # RCCL refuses two ranks on one device
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
 def init_rank(world, local_rank):
     """One process per GPU: bind this rank to its device and join the RCCL group (backend "nccl" is RCCL on ROCm).
     FS2_BENCH_BACKEND=gloo + FS2_BENCH_SHARE_GPU=1 exist only so that the N>1 code path can be exercised by the tests on a
@@ -486,14 +509,13 @@ def pmc_traffic(kernel_substr):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     if args.mode == "synth":
         return synth_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
     import torch.distributed as dist
     lib_used = dev_environment()
     device = init_rank(world, local_rank)

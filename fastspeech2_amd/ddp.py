@@ -20,8 +20,12 @@ import torch.distributed as dist
 
 class GradExchange:
     def __init__(self, flat_grad, world_size=None, bucket_bytes=32 << 20, group=None, overlap=True, tail_bucket_bytes=None,
-                 tail_bytes=48 << 20):
-        """Buckets are `bucket_bytes` except over the LAST `tail_bytes` of the flat buffer (the encoder's gradients, final only
+                 tail_bytes=48 << 20, collectives=None):
+        """`collectives`: None = issue the all-reduces whenever a process group exists - ALSO over a one-rank group (the identity
+        reduction costs one small RCCL launch per bucket and keeps the one-rank run the same program as the N-rank run); without a
+        process group there is nothing to call and the exchange is a no-op.  False forces the no-op, True insists on a group.
+
+        Buckets are `bucket_bytes` except over the LAST `tail_bytes` of the flat buffer (the encoder's gradients, final only
         when backward ends), which travel in `tail_bucket_bytes` pieces (default bucket_bytes / 4): whatever is still in flight
         when backward finishes is exposed in front of the clip + Adam pass (it needs the norm of ALL gradients, so it cannot
         start per bucket), and a smaller last piece makes that exposure a quarter of a bucket instead of a whole one."""
@@ -33,16 +37,23 @@ class GradExchange:
         tb = tail_bucket_bytes if tail_bucket_bytes is not None else max(1, bucket_bytes // 4)
         self.tail_elems = max(1, tb // flat_grad.element_size())
         self.tail_start = max(0, self.n - tail_bytes // flat_grad.element_size())
+        have_pg = dist.is_available() and dist.is_initialized()
+        # world > 1 without a group stays "active": the first all_reduce then raises instead of silently training unsynchronised
+        self.active = (have_pg or self.world > 1) if collectives is None else bool(collectives)
         self.cuda = flat_grad.is_cuda
         self.overlap = overlap and self.cuda
         # high priority: the collective's few workgroups must get CUs while backward still fills the device, otherwise the
         # exchange only starts moving once compute drains and nothing overlaps
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device, priority=-1) if self.cuda else None
+        self.n_buckets = 0           # all_reduce calls issued so far (cumulative)
+        self.last_step = (0, 0)      # (buckets launched by ready() = under backward, buckets launched by finish()) of the last step
+        self._early = 0
         self.reset()
 
     def reset(self):
         self.sent = 0          # prefix [0, sent) already handed to the collective
         self.handles = []
+        self._early = 0
 
     def _launch(self, lo, hi, producers=()):
         view = self.flat[lo:hi]
@@ -62,11 +73,12 @@ class GradExchange:
             view.div_(self.world)
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)
+        self.n_buckets += 1
 
     def ready(self, end, producers=()):
         """Engine hook: gradients in flat[0:end) are final once the work queued so far on the current stream and on every
         stream in `producers` has run.  Launch every full bucket inside that prefix."""
-        if self.world == 1:
+        if not self.active:
             return
         end = min(end, self.n)
         while True:
@@ -75,15 +87,19 @@ class GradExchange:
                 break
             self._launch(self.sent, self.sent + size, producers)
             self.sent += size
+            self._early += 1
 
     def finish(self):
         """Flush the tail bucket and make the compute stream wait for all collectives."""
-        if self.world == 1:
+        if not self.active:
             self.reset()
             return
+        late = 0
         if self.sent < self.n:
             self._launch(self.sent, self.n)
             self.sent = self.n
+            late = 1
+        self.last_step = (self._early, late)
         for h in self.handles:
             h.wait()
         if self.cuda and self.overlap:
@@ -105,7 +121,7 @@ class CountExchange:
         self._stream = None
 
     def start(self, src_lens, mel_lens, L, T):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized():
             return
         c = torch.stack([src_lens.to(torch.int64).clamp(max=L).sum(), mel_lens.to(torch.int64).clamp(max=T).sum()]).float()
         if c.is_cuda:
@@ -133,7 +149,7 @@ class CountExchange:
 def global_counts(counts, group=None):
     """all-reduce (sum) a small tensor of valid-position counts; returns counts / world (so that a local loss
     normalised by it, averaged over ranks, equals the global-batch mean)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return counts
     c = counts.clone().float()
     dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)

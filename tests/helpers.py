@@ -35,6 +35,50 @@ def oracle_train_case(pcfg, mcfg, sd, b, dtype=torch.float32):
     return out, losses, grads, bn_buffers
 
 
+def oracle_gathered_case(pcfg, mcfg, sd, batches, dtype=torch.float64):
+    """What the reference's nn.DataParallel step computes (train.py:42, 82-86): every replica runs the module on ITS chunk of the
+    batch (train-mode BatchNorm statistics are therefore per replica), the outputs are gathered, ONE loss is taken over the gathered
+    batch (masked means over ALL valid positions), and backward sums the replicas' parameter gradients.  `batches` = one oracle
+    batch dict per replica; outputs are padded to the longest replica before the concatenation (masked positions never enter the
+    loss).  Returns (losses, grads of the gathered-batch loss)."""
+    sdr = {k: (v.to(dtype) if v.is_floating_point() else v).clone() for k, v in sd.items()}
+    leaves = {}
+    for k, v in sdr.items():
+        if v.is_floating_point() and not any(s in k for s in ("position_enc", "_bins", "running_")):
+            v.requires_grad_(True)
+            leaves[k] = v
+    outs = []
+    for b in batches:
+        bn_buffers = {k: v.clone() for k, v in sdr.items() if "running_" in k}
+        outs.append(O.fastspeech2_forward(sdr, mcfg, pcfg, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"],
+                                          b["mels"].to(dtype), b["mel_lens"], b["max_mel_len"], b["pitches"].to(dtype),
+                                          b["energies"].to(dtype), b["durations"], training=True, dropout=False, bn_buffers=bn_buffers))
+    L = max(o[6].shape[1] for o in outs)
+    T = max(o[7].shape[1] for o in outs)
+
+    def pad(x, n, value=0):
+        """pad dim 1 to n"""
+        if x.shape[1] == n:
+            return x
+        shp = list(x.shape)
+        shp[1] = n - x.shape[1]
+        return torch.cat([x, torch.full(shp, value, dtype=x.dtype)], 1)
+
+    frame_p = pcfg["preprocessing"]["pitch"]["feature"] != "phoneme_level"
+    frame_e = pcfg["preprocessing"]["energy"]["feature"] != "phoneme_level"
+    gathered = (torch.cat([pad(o[0], T) for o in outs]), torch.cat([pad(o[1], T) for o in outs]),
+                torch.cat([pad(o[2], T if frame_p else L) for o in outs]), torch.cat([pad(o[3], T if frame_e else L) for o in outs]),
+                torch.cat([pad(o[4], L) for o in outs]), None,
+                torch.cat([pad(o[6], L, True) for o in outs]), torch.cat([pad(o[7], T, True) for o in outs]), None, None)
+    targets = (torch.cat([pad(b["mels"].to(dtype), T) for b in batches]),
+               torch.cat([pad(b["pitches"].to(dtype), T if frame_p else L) for b in batches]),
+               torch.cat([pad(b["energies"].to(dtype), T if frame_e else L) for b in batches]),
+               torch.cat([pad(b["durations"], L) for b in batches]))
+    losses = O.fastspeech2_loss(pcfg, targets, gathered)
+    losses[0].backward()
+    return losses, {k: v.grad for k, v in leaves.items() if v.grad is not None}
+
+
 def bf16_matrix(name, v):
     """the parameters the bf16 engine holds a bf16 copy of and multiplies in bf16: the weights of its MFMA contractions (Linear /
     Conv1d of the FFT blocks, variance predictors' convs, mel_linear, PostNet convs: Engine._conv_list).  Embedding tables, the

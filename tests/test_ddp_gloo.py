@@ -124,12 +124,60 @@ def test_world2_gloo_exchange_loss_and_sharding():
 
 
 def test_single_process_exchange_is_identity():
+    """WITHOUT a process group there is no collective to call: the exchange is a no-op (plain single-GPU training)."""
     flat = torch.arange(100, dtype=torch.float32)
     ex = ddp.GradExchange(flat.clone(), world_size=1)
+    assert ex.active is False
     ex.ready(50)
     ex.finish()
-    assert torch.equal(ex.flat, flat)
+    assert torch.equal(ex.flat, flat) and ex.n_buckets == 0
     assert torch.equal(ddp.global_counts(torch.tensor([3.0])), torch.tensor([3.0]))
+
+
+def _one_rank_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = [0]
+        real = dist.all_reduce
+
+        def counted(*a, **k):
+            calls[0] += 1
+            return real(*a, **k)
+        dist.all_reduce = counted
+        flat = torch.arange(10007, dtype=torch.float32)
+        ex = ddp.GradExchange(flat.clone(), bucket_bytes=4000, tail_bytes=10000)      # world size from the group: 1
+        ex.ready(5000)
+        early = ex.n_buckets
+        ex.ready(10007)
+        ex.finish()
+        ce = ddp.CountExchange()
+        ce.start(torch.tensor([3, 5]), torch.tensor([7, 9]), 4, 8)
+        c = ce(torch.tensor([0.0, 0.0]))
+        g = ddp.global_counts(torch.tensor([2.0, 3.0]))
+        q.put(dict(active=ex.active, world=ex.world, early=early, n_buckets=ex.n_buckets, last_step=ex.last_step, calls=calls[0],
+                   same=bool(torch.equal(ex.flat, flat)), counts=c.tolist(), g=g.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_one_rank_group_issues_every_collective():
+    """with a process group of ONE rank the exchange used to return early everywhere, so a "one-rank RCCL"
+    run never called all_reduce.  Now a group - of any size - means real collectives: every bucket, the tail, the counts."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=100)
+    p.join(30)
+    assert p.exitcode == 0
+    assert r["active"] is True and r["world"] == 1 and r["same"]
+    # 10007 floats: tail region = last 2500 -> 1000-float buckets up to 7000 (7), 250-float pieces after (12), 7 floats in finish()
+    assert r["early"] == 5 and r["n_buckets"] == 7 + 12 + 1 and r["last_step"] == (19, 1)
+    assert r["calls"] == r["n_buckets"] + 2                      # + CountExchange.start + global_counts
+    assert r["counts"] == [7.0, 15.0] and r["g"] == [2.0, 3.0]
 
 
 def test_bucket_schedule_at_the_real_parameter_layout():

@@ -3,6 +3,7 @@ gloo (it carries device tensors through the host; RCCL refuses two ranks on one 
 8-GPU run uses - engine prefix hooks, side-stream joins, bucketed overlapped all-reduce, globally normalised loss, fused
 clip+Adam - and checks it against a single process that sees both ranks' batches:
     averaged DP gradient == mean of the two per-batch gradients computed with the global counts   (fp32, dropout off)
+    averaged DP gradient == the ORACLE's gradient of the reference's gathered-batch loss (two replicas, per-replica BatchNorm)
     parameters after the step are identical on both ranks and equal to the single-process update."""
 import os
 import socket
@@ -63,9 +64,10 @@ def _worker(rank, world, port, q):
             ex.finish()
             if _ == 0:
                 g1 = model.flat_gradients().clone()
+                named = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.grad is not None}
             opt.step_and_update_lr(zero_grad=True)
         torch.cuda.synchronize()
-        q.put((rank, g1.cpu().numpy(), model.flat_parameters().detach().cpu().numpy()))     # by value: the worker exits
+        q.put((rank, g1.cpu().numpy(), model.flat_parameters().detach().cpu().numpy(), named))     # by value: the worker exits
     finally:
         dist.destroy_process_group()
 
@@ -80,8 +82,8 @@ def test_two_rank_step_matches_single_process(dev):
         p.start()
     res = {}
     for _ in range(world):
-        r, g, p = q.get(timeout=600)
-        res[r] = (torch.from_numpy(g), torch.from_numpy(p))
+        r, g, p, named = q.get(timeout=600)
+        res[r] = (torch.from_numpy(g), torch.from_numpy(p), named)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -104,3 +106,25 @@ def test_two_rank_step_matches_single_process(dev):
     gref = (gsum / world).cpu()
     g = res[0][0]
     assert (g - gref).abs().max().item() <= 2e-5 * gref.abs().max().item() + 1e-9
+
+    # ... and against the ORACLE of what the reference's DataParallel step differentiates (train.py:42, 82-86): one loss over the
+    # gathered outputs of two replicas, each with its own train-mode BatchNorm statistics (the comparison above
+    # is product vs product).  The exchanged gradient is the rank AVERAGE of gradients of losses normalised by (global count /
+    # world) = the gradient of the gathered-batch loss itself.
+    from oracle.weights import seeded_state_dict, synthetic_batch
+    from tests.helpers import oracle_gathered_case
+    sd = seeded_state_dict(model.state_dict(), 3)
+    batches = [synthetic_batch(50 + r, 3, 20 + 4 * r) for r in range(world)]
+    _, ograds = oracle_gathered_case(pcfg, mcfg, sd, batches)
+    named = res[0][2]
+    assert set(ograds) <= set(named) | {n for n in ograds if n.endswith("w_ks.bias")}
+    checked = 0
+    for n, og in ograds.items():
+        if n.endswith("w_ks.bias"):                       # exactly zero in exact arithmetic (softmax shift invariance)
+            continue
+        gp = torch.from_numpy(named[n]).double()
+        scale = og.abs().max().item()
+        err = (gp - og).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, (n, err, scale)
+        checked += 1
+    assert checked >= 100
