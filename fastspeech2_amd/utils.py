@@ -94,13 +94,36 @@ def get_vocoder(config, device, hifigan_dir="hifigan", compute_dtype="fp32", all
     return vocoder
 
 
+_PCM_HOST = {}
+
+
+def _pinned_like(t):
+    """a pinned host buffer for `t` (kept per shape / dtype and reused: pinning costs more than the copy)"""
+    key = (tuple(t.shape), t.dtype)
+    buf = _PCM_HOST.get(key)
+    if buf is None:
+        if len(_PCM_HOST) > 64:
+            _PCM_HOST.clear()
+        buf = _PCM_HOST[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    return buf
+
+
 def vocoder_infer(mels, vocoder, model_config, preprocess_config, lengths=None):
-    """utils/model.py:74-92: mels (B, 80, T) -> list of int16 numpy arrays (cut to `lengths` samples)."""
+    """utils/model.py:74-92: mels (B, 80, T) -> list of int16 numpy arrays (cut to `lengths` samples).
+    `lengths` may be a device tensor: it is read AFTER the vocoder's launches are queued (the reference's `.tolist()` in front of
+    the vocoder is a device round trip with an idle GPU behind it), and the PCM comes back in ONE asynchronous copy into pinned
+    memory (a pageable `.cpu()` of a batch's 2-3 MB is staged by the runtime in ~30 KB pieces: ~90 copy kernels per batch)."""
     name = model_config["vocoder"]["model"]
     assert name == "HiFi-GAN"
     with torch.no_grad():
         pcm = vocoder.infer_pcm(mels, preprocess_config["preprocessing"]["audio"]["max_wav_value"])
-    wavs = [w for w in pcm.cpu().numpy()]
+        host = _pinned_like(pcm)
+        host.copy_(pcm, non_blocking=True)
+        if torch.is_tensor(lengths):
+            lengths = lengths.tolist()                       # (synchronises: the copy above has landed behind it)
+        else:
+            torch.cuda.current_stream(pcm.device).synchronize()
+    wavs = [w.copy() for w in host.numpy()]                  # (the pinned buffer is reused by the next batch)
     for i in range(len(mels)):
         if lengths is not None:
             wavs[i] = wavs[i][: lengths[i]]
@@ -169,7 +192,7 @@ def synth_samples(targets, predictions, vocoder, model_config, preprocess_config
     basenames = targets[0]
     mel_predictions = predictions[1].transpose(1, 2)                     # (B, 80, T) view — zero-copy into the vocoder
     lengths = predictions[9] * preprocess_config["preprocessing"]["stft"]["hop_length"]
-    wavs = vocoder_infer(mel_predictions, vocoder, model_config, preprocess_config, lengths=lengths.tolist())
+    wavs = vocoder_infer(mel_predictions, vocoder, model_config, preprocess_config, lengths=lengths)
     if write:
         os.makedirs(path, exist_ok=True)
         sr = preprocess_config["preprocessing"]["audio"]["sampling_rate"]

@@ -113,7 +113,7 @@ def test_two_rank_step_matches_single_process(dev):
     # world) = the gradient of the gathered-batch loss itself.
     from oracle.weights import seeded_state_dict, synthetic_batch
     from tests.helpers import oracle_gathered_case
-    sd = seeded_state_dict(model.state_dict(), 3)
+    sd = seeded_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, 3)
     batches = [synthetic_batch(50 + r, 3, 20 + 4 * r) for r in range(world)]
     _, ograds = oracle_gathered_case(pcfg, mcfg, sd, batches)
     named = res[0][2]

@@ -31,13 +31,24 @@ def main():
                        f"group by {name}, stream_id order by 2 desc").fetchall()
         print(f"## {db.split('/')[-1]}: {len(ad)} optimiser steps\n")
         if not cc:
-            print("NO RCCL kernel in this trace\n")
-            continue
+            # a ONE-rank communicator reduces in place over one rank: RCCL has nothing to move and launches no device kernel for
+            # it (the calls are still made and counted - tests/test_nccl_gpu.py); what the trace does show is each bucket's scaling
+            # kernel (view.div_(world): MulFunctor) on the communication stream, i.e. WHEN every bucket was handed to RCCL
+            print("no RCCL device kernel in this trace (one-rank communicator: in-place all_reduce over one rank moves nothing); "
+                  "showing the buckets' scaling kernels on the communication stream instead\n")
+            pat = "mulfunctor"
+        else:
+            pat = None
+        hit = (lambda n: pat in n.lower()) if pat else (lambda n: "nccl" in n.lower() or "rccl" in n.lower())
         for n, k, sid, avg in cc:
             print(f"- `{n[:110]}`: {k} launches on stream {sid}, {avg / 1e3:.1f} us average")
         st = c.execute("select stream_id, count(*) from kernels group by stream_id order by 2 desc").fetchall()
         print(f"\nstreams by kernel count: {st} (first = the step's stream, second = the weight-gradient side stream)\n")
         main_s = st[0][0]
+        if pat:
+            ex = c.execute(f"select stream_id, count(*) from kernels where lower({name}) like '%mulfunctor%' and stream_id != ? group by stream_id order by 2 desc", (main_s,)).fetchone()
+            print(f"communication stream: {ex[0] if ex else None} ({ex[1] if ex else 0} bucket scalings)\n")
+            comm_s = ex[0] if ex else None
         print("| step | backward: loss_bwd start -> last main-stream kernel before clip (us) | RCCL kernels in that window: count, stream(s) | start offsets (us) | started before backward's end | sum of durations (us) | clip start - backward end (us) |")
         print("|---|---|---|---|---|---|---|")
         for i in range(1, len(ad)):
@@ -47,7 +58,7 @@ def main():
             if b0 is None or clip is None:
                 continue
             mend = max(e for n, s, e, sid in ks if sid == main_s and b0 <= s < clip)
-            rc = [(s, e, sid) for n, s, e, sid in ks if ("nccl" in n.lower() or "rccl" in n.lower()) and b0 <= s <= clip + 1]
+            rc = [(s, e, sid) for n, s, e, sid in ks if hit(n) and (pat is None or sid == comm_s) and b0 <= s <= clip + 1]
             if not rc:
                 continue
             under = sum(1 for s, e, sid in rc if s < mend)
