@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph-line", action="store_true", help="skip the hipGraph replay of the same step reported beside the eager number")
     ap.add_argument("--no-synth", action="store_true", help="train mode: skip the batch-synthesis RTF object (config.synth)")
+    ap.add_argument("--no-fuse-resblocks", action="store_true", help="synthesis A/B: HiFi-GAN's narrow-stage residual blocks as six launches "
+                                                                      "each (the round-4 path) instead of one fused launch")
     ap.add_argument("--cpu-threads", default="8,16,32,64", help="torch thread counts the CPU baseline sweeps (those <= cpu_count)")
     a = ap.parse_args(argv)
     argv = sys.argv if argv is None else argv
@@ -336,6 +338,7 @@ def synth_measure(args, device, rank, world, steps, warmup, want_roofline):
     voc.eval()
     voc.remove_weight_norm()
     voc.to(device)
+    voc.fuse_resblocks = not args.no_fuse_resblocks
     B = args.synth_batch
     counts = val_phoneme_counts()
     groups = [counts[i:i + B] for i in range(0, len(counts), B)][rank::world]

@@ -100,6 +100,7 @@ class Generator(nn.Module):
         self.conv_post = _WNConv((1, c0 // (2 ** self.num_upsamples), 7), c0 // (2 ** self.num_upsamples) * 7)
         self.set_compute_dtype(compute_dtype)
         self._packed = None
+        self.fuse_resblocks = True       # False: every convolution of the narrow stages as its own launch (A/B, parity tests)
         self.stage_probe = None          # a list: _run appends the output rows of conv_pre and of every up-sampling stage (tests)
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
@@ -162,6 +163,16 @@ class Generator(nn.Module):
             for m in range(len(rb.dilations)):
                 W[f"rb{j}.1.{m}"] = self._pack_conv(rb.convs1[m], dev, cdt)
                 W[f"rb{j}.2.{m}"] = self._pack_conv(rb.convs2[m], dev, cdt)
+        # the narrow stages' residual blocks run as ONE launch each (fs2_resblock_fwd): convs1 / convs2 stacked [3][C][k][C]
+        lib = _lib.load()
+        for j, rb in enumerate(self.resblocks):
+            C = rb.convs1[0].bias.shape[0]
+            nd = len(rb.dilations)
+            if nd == 3 and lib.fs2_resblock_supported(C, rb.kernel_size, *rb.dilations, ops.dt(cdt)):
+                W[f"rb{j}.fused"] = (torch.stack([W[f"rb{j}.1.{m}"][0] for m in range(nd)]).contiguous(),
+                                     torch.stack([W[f"rb{j}.2.{m}"][0] for m in range(nd)]).contiguous(),
+                                     torch.stack([W[f"rb{j}.1.{m}"][1] for m in range(nd)]).contiguous(),
+                                     torch.stack([W[f"rb{j}.2.{m}"][1] for m in range(nd)]).contiguous())
         wpost = self.conv_post.effective_weight().detach().to(dev, torch.float32)   # (1, C, 7)
         W["post"] = (wpost[0].t().contiguous(), self.conv_post.bias.detach().to(dev, torch.float32).contiguous())
         self._packed = (key, W)
@@ -188,6 +199,17 @@ class Generator(nn.Module):
             for j in range(nk):
                 rb = self.resblocks[i * nk + j]
                 rk = rb.kernel_size
+                fused = W.get(f"rb{i * nk + j}.fused") if self.fuse_resblocks else None
+                if fused is not None:               # the whole block in one launch (x read once, xs read + written once)
+                    if xs is None:
+                        xs = torch.empty_like(x)
+                        acc = False
+                    else:
+                        acc = True
+                    _lib.call("fs2_resblock_fwd", x.data_ptr(), x.stride(0), fused[0].data_ptr(), fused[1].data_ptr(),
+                              fused[2].data_ptr(), fused[3].data_ptr(), xs.data_ptr(), xs.stride(0), int(acc), 1.0 / nk, LRELU_SLOPE,
+                              B, S, x.shape[1], rk, *rb.dilations, ops.dt(x), ops._stream())
+                    continue
                 cur = x
                 nd = len(rb.dilations)
                 for m, d in enumerate(rb.dilations):

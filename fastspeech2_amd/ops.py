@@ -132,6 +132,18 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     return out
 
 
+def resblock_fwd(x, w1, w2, b1, b2, B, S, k, dilations, xs=None, out_scale=1.0, slope=0.1):
+    """a whole HiFi-GAN ResBlock1 (hifigan/models.py:96-103) on rows x [B*S][C] in one launch (fs2_resblock_fwd; C in {32, 64}, bf16):
+    xs = (xs if given else 0) + out_scale * block(x).  w1 / w2: [3][C][k][C], b1 / b2: [3][C] f32."""
+    acc = xs is not None
+    if xs is None:
+        xs = torch.empty_like(x)
+    d0, d1, d2 = dilations
+    _lib.call("fs2_resblock_fwd", _p(x), x.stride(0), _p(w1), _p(w2), _p(b1), _p(b2), _p(xs), xs.stride(0), int(acc), out_scale, slope,
+              B, S, x.shape[1], k, d0, d1, d2, dt(x), _stream())
+    return xs
+
+
 def conv_gemm_tall(x, wpacked, bias, S, taps, pad, act=ACT_NONE, slope=0.0, res=None, out=None, accumulate=False, out_scale=1.0,
                    tail_ws=None):
     """the 512 x 128 tall-tile kernel by name (fs2_conv_gemm_tall): parity test / A-B tool only - conv_gemm never dispatches to it"""

@@ -245,6 +245,15 @@ int fs2_chan_to_rows(const float* in, void* out, int B, int C, int T, int dtype,
 int fs2_conv_post_pcm(const void* x, long ldx, const float* w, const float* bias, float in_slope, float* wav,
                       int16_t* pcm, float max_wav_value, int M, int S, int C, int taps, int pad, int dtype,
                       fs2_stream_t stream);
+/* hifigan/models.py:96-103 + 155-160: a whole ResBlock1 of the narrow stages (C = 32 / 64, bf16) in ONE launch -
+ *   y = x; for m in 0..2: t = lrelu(conv1_m(lrelu(y), dilation d_m)); y = conv2_m(t) + y;  xs = (accumulate ? xs : 0) + out_scale * y
+ * x / xs: rows [B*S][C] (time-major); w1 / w2: [3][C][k][C] (convs1 / convs2 of the block, cout-major, tap, cin), b1 / b2: [3][C] f32.
+ * The running sum stays in fp32 registers, the convolutions' operands in LDS: x is read once, xs read + written once.
+ * fs2_resblock_supported: 1 when a (C, k, dilations, dtype) combination has an instantiation (else run the convolutions one by one). */
+int fs2_resblock_supported(int C, int k, int d0, int d1, int d2, int dtype);
+int fs2_resblock_fwd(const void* x, long ldx, const void* w1, const void* w2, const float* b1, const float* b2, void* xs,
+                     long ldxs, int accumulate, float out_scale, float slope, int B, int S, int C, int k, int d0, int d1, int d2,
+                     int dtype, fs2_stream_t stream);
 /* stft.py:60-66: xp[b][i] = y[b][reflect(i - P)], i < N + 2P; zero-filled up to row_len. */
 int fs2_reflect_pad(const float* y, float* xp, int B, int N, int P, long row_len, fs2_stream_t stream);
 /* The same for a ragged batch (preprocessor/preprocessor.py:194 over a corpus): row b holds lens[b] samples (row stride ldy,
