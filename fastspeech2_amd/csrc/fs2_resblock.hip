@@ -26,11 +26,13 @@ typedef unsigned rb_u32x2 __attribute__((ext_vector_type(2)));
 
 struct ResBlockArgs {
     const void* X; long ldx;            // [M][C] bf16 (M = B * S rows, time-major)
-    const void* W1; const void* W2;     // [3][C][k][C] bf16 each (conv index, cout, tap, cin)
-    const float* B1; const float* B2;   // [3][C] f32
+    // up to three blocks on the same x (the kernel sizes 3 / 7 / 11 of one up-sampling stage, models.py:155-160), same dilations
+    const void* W1[3]; const void* W2[3];   // per block: [3][C][k][C] bf16 (conv index, cout, tap, cin)
+    const float* B1[3]; const float* B2[3]; // per block: [3][C] f32
+    int k[3], nblk;
     void* XS; long ldxs;                // [M][C] bf16
     int accumulate; float out_scale, slope;
-    int S, nbatch, k, d[3], R, tiles_per_seq;
+    int S, nbatch, d[3], R, tiles_per_seq;
 };
 
 template <int C> struct RbCfg {
@@ -43,7 +45,7 @@ template <int C> struct RbCfg {
     static constexpr int ACT_BYTES = (E + 2 * GUARD) * ROWB;
     static constexpr int W_OFF = ACT_BYTES, SLOT = TG * TAPB;
     static constexpr int BIAS_OFF = W_OFF + 2 * SLOT;
-    static constexpr int LDS = BIAS_OFF + 6 * C * 4;
+    static constexpr int LDS = BIAS_OFF + 18 * C * 4;
     static constexpr int PPT = TAPB / 1024;                  // 1 KiB DMA pieces per tap (2 / 8)
 };
 // swizzle key of LDS row r: chunk c is stored at chunk c ^ key (16 consecutive rows x one chunk -> 16 distinct 16-byte slots of the
@@ -68,15 +70,19 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
     const int H = (E - a.R) >> 1;
     const int t_first = tile * a.R - H;                      // utterance row of tile row 0
     const size_t seq_row0 = (size_t)seq * a.S;
-    const int k = a.k, pad2 = (k - 1) >> 1;
-
-    // ---- weight stream: group gi -> slot gi & 1.  conv c = 2m (conv1 of pair m) / 2m + 1 (conv2); groups of <= TG taps
-    const int gpc = (k + TG - 1) / TG;                       // groups per convolution
-    const int ngroups = 6 * gpc;
+    // ---- weight stream over all blocks: group gi -> slot gi & 1.  Block j: convolution c = 2m (conv1 of pair m) / 2m + 1 (conv2), each
+    // in gpc_j = ceil(k_j / TG) groups of <= TG taps
+    int gpc[3], gstart[4];
+    gstart[0] = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { gpc[j] = j < a.nblk ? (a.k[j] + TG - 1) / TG : 0; gstart[j + 1] = gstart[j] + 6 * gpc[j]; }
+    const int ngroups = gstart[3];
     auto issue_group = [&](int gi) {
-        const int c = gi / gpc, g = gi - c * gpc;
-        const int tap0 = g * TG, nt = min(TG, k - tap0);
-        const unsigned char* wbase = reinterpret_cast<const unsigned char*>((c & 1) ? a.W2 : a.W1) + (size_t)(c >> 1) * C * k * C * 2;
+        const int j = gi >= gstart[2] ? 2 : (gi >= gstart[1] ? 1 : 0);
+        const int kj = a.k[j], gl = gi - gstart[j];
+        const int c = gl / gpc[j], g = gl - c * gpc[j];
+        const int tap0 = g * TG, nt = min(TG, kj - tap0);
+        const unsigned char* wbase = reinterpret_cast<const unsigned char*>((c & 1) ? a.W2[j] : a.W1[j]) + (size_t)(c >> 1) * C * kj * C * 2;
         const unsigned slot = smem_u + K::W_OFF + (unsigned)((gi & 1) * K::SLOT);
         const int npieces = nt * K::PPT;
         for (int q = wave; q < npieces; q += 8) {
@@ -85,32 +91,16 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
             const int cout = p * (C / K::PPT) + lane / K::CPR;
             const unsigned pos = (unsigned)(lane % K::CPR);
             const unsigned gch = pos ^ rb_key<C>((unsigned)cout);
-            const unsigned voff = (unsigned)(((cout * k + tap0 + tl) * C) * 2) + (gch << 4);
+            const unsigned voff = (unsigned)(((cout * kj + tap0 + tl) * C) * 2) + (gch << 4);
             glds16_sbase(voff, wbase, __builtin_amdgcn_readfirstlane(slot + (unsigned)(tl * K::TAPB + p * 1024)));
         }
     };
     issue_group(0);
-    for (int i = tid; i < 6 * C; i += 512) {
-        const int c = i / C, n = i - c * C;
-        bias_s[i] = ((c & 1) ? a.B2 : a.B1)[(c >> 1) * C + n];
+    for (int i = tid; i < a.nblk * 6 * C; i += 512) {
+        const int j = i / (6 * C), r = i - j * 6 * C, c = r / C, n = r - c * C;
+        bias_s[i] = ((c & 1) ? a.B2[j] : a.B1[j])[(c >> 1) * C + n];
     }
 
-    // ---- y <- x: this wave's rows, accumulator layout (lane = row, registers = couts 4 fh + (r & 3) + 8 (r >> 2))
-    f32x16 y[MB][NB];
-    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int tr = wave * (MB * 32) + mb * 32 + fl;
-        const int t = min(max(t_first + tr, 0), a.S - 1);
-        const bf16_t* row = X + (seq_row0 + (size_t)t) * a.ldx;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = ld4<bf16_t>(row + nb * 32 + 8 * q + 4 * fh);
-                y[mb][nb][4 * q + 0] = v.x; y[mb][nb][4 * q + 1] = v.y; y[mb][nb][4 * q + 2] = v.z; y[mb][nb][4 * q + 3] = v.w;
-            }
-    }
     // rows of this lane inside the utterance? (bit mb)
     unsigned in_seq = 0;
 #pragma unroll
@@ -118,7 +108,33 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
         const int t = t_first + wave * (MB * 32) + mb * 32 + fl;
         if (t >= 0 && t < a.S) in_seq |= 1u << mb;
     }
-
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
+    bf16_t* XS = reinterpret_cast<bf16_t*>(a.XS);
+    // this lane's rows in the accumulator layout (lane = row, registers = couts 4 fh + (r & 3) + 8 (r >> 2)): 8-byte pieces
+    auto load_rows = [&](const bf16_t* base, long ld, f32x16 (&v)[MB][NB]) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int t = min(max(t_first + wave * (MB * 32) + mb * 32 + fl, 0), a.S - 1);
+            const bf16_t* row = base + (seq_row0 + (size_t)t) * ld;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 x4 = ld4<bf16_t>(row + nb * 32 + 8 * q + 4 * fh);
+                    v[mb][nb][4 * q + 0] = x4.x; v[mb][nb][4 * q + 1] = x4.y; v[mb][nb][4 * q + 2] = x4.z; v[mb][nb][4 * q + 3] = x4.w;
+                }
+        }
+    };
+    // accumulator layout -> a lane's 2 x 8 consecutive couts (chunks nb * 4 + ch * 2 + fh) of its row
+    auto to_rows = [&](const f32x16& v, float (&c)[2][8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rb_u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[e]), __float_as_uint(v[4 + e]), false, false);
+            rb_u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 + e]), __float_as_uint(v[12 + e]), false, false);
+            c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
+            c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
+        }
+    };
     // LDS row of tile row tr: GUARD + tr.  Write lrelu(v) (bf16, zeros outside the utterance) for this wave's rows.
     auto write_act = [&](f32x16 (&v)[MB][NB]) {
 #pragma unroll
@@ -129,13 +145,7 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 float c[2][8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    rb_u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[mb][nb][e]), __float_as_uint(v[mb][nb][4 + e]), false, false);
-                    rb_u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[mb][nb][8 + e]), __float_as_uint(v[mb][nb][12 + e]), false, false);
-                    c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
-                    c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
-                }
+                to_rows(v[mb][nb], c);
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch) {
                     uint4 o;
@@ -152,34 +162,50 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
             }
         }
     };
-    write_act(y);
 
-    // ---- the six convolutions
-    f32x16 t_acc[MB][NB];
+    f32x16 y[MB][NB], t_acc[MB][NB];
+    uint32_t xs_pk[MB][NB][8];                              // the running xs, bf16 pairs of accumulator registers (2i, 2i + 1)
+    if (a.accumulate) {
+        load_rows(XS, a.ldxs, t_acc);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xs_pk[mb][nb][i] = pack_bf16x2(t_acc[mb][nb][2 * i], t_acc[mb][nb][2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xs_pk[mb][nb][i] = 0u;
+    }
     unsigned wkey[NB], wrow[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) { wrow[nb] = (unsigned)((nb * 32 + fl) * ROWB); wkey[nb] = rb_key<C>((unsigned)(nb * 32 + fl)); }
     int gi = 0;
-    // the groups of convolution c multiplied into `acc` (y for conv2: the residual is already in it; t_acc for conv1)
-    auto run_conv = [&](f32x16 (&acc)[MB][NB], int c, bool add_bias) {
+    // the groups of convolution c of block j multiplied into `acc` (y for conv2: the residual is already in it; t_acc for conv1)
+    auto run_conv = [&](f32x16 (&acc)[MB][NB], int j, int c, bool add_bias) {
+        const int kj = a.k[j], pad2 = (kj - 1) >> 1;
         const int dil = (c & 1) ? 1 : a.d[c >> 1];
         const int pad = pad2 * dil;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias_s + c * C + nb * 32 + 8 * q + 4 * fh);
+                const float4 bv = *reinterpret_cast<const float4*>(bias_s + (j * 6 + c) * C + nb * 32 + 8 * q + 4 * fh);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     if (add_bias) { acc[mb][nb][4 * q] += bv.x; acc[mb][nb][4 * q + 1] += bv.y; acc[mb][nb][4 * q + 2] += bv.z; acc[mb][nb][4 * q + 3] += bv.w; }
                     else { acc[mb][nb][4 * q] = bv.x; acc[mb][nb][4 * q + 1] = bv.y; acc[mb][nb][4 * q + 2] = bv.z; acc[mb][nb][4 * q + 3] = bv.w; }
                 }
             }
-        for (int g = 0; g < gpc; ++g, ++gi) {
+        for (int g = 0; g < gpc[j]; ++g, ++gi) {
             rb_barrier_all();                  // my pieces of group gi landed (nothing younger in flight), my tile rows stored; then:
                                                // group gi + the activation tile visible to all, slot (gi + 1) & 1 free
             if (gi + 1 < ngroups) issue_group(gi + 1);
-            const int tap0 = g * TG, nt = min(TG, k - tap0);
+            const int tap0 = g * TG, nt = min(TG, kj - tap0);
             const unsigned wslot = (unsigned)(K::W_OFF + (gi & 1) * K::SLOT);
             for (int tl = 0; tl < nt; ++tl) {
                 const int shift = (tap0 + tl) * dil - pad;
@@ -210,18 +236,33 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
             }
         }
     };
-    for (int m = 0; m < 3; ++m) {
-        run_conv(t_acc, 2 * m, false);
-        rb_barrier_lds();                      // every wave has read lrelu(y): the tile may be overwritten
-        write_act(t_acc);
-        run_conv(y, 2 * m + 1, true);
-        if (m == 2) break;
-        rb_barrier_lds();
+    for (int j = 0; j < a.nblk; ++j) {
+        load_rows(X, a.ldx, y);                // y <- x (blocks after the first: from L2)
+        if (j > 0) rb_barrier_lds();           // every wave has finished the previous block's last convolution
         write_act(y);
+        for (int m = 0; m < 3; ++m) {
+            run_conv(t_acc, j, 2 * m, false);
+            rb_barrier_lds();                  // every wave has read lrelu(y): the tile may be overwritten
+            write_act(t_acc);
+            run_conv(y, j, 2 * m + 1, true);
+            if (m == 2) break;
+            rb_barrier_lds();
+            write_act(y);
+        }
+        // xs <- bf16(xs + out_scale * y): rounded after every block, as the chain of launches stored it
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t u = xs_pk[mb][nb][i];
+                    xs_pk[mb][nb][i] = pack_bf16x2(__uint_as_float(u << 16) + a.out_scale * y[mb][nb][2 * i],
+                                                   __uint_as_float(u & 0xffff0000u) + a.out_scale * y[mb][nb][2 * i + 1]);
+                }
     }
 
-    // ---- xs (+)= out_scale * y for the tile's central R rows
-    bf16_t* XS = reinterpret_cast<bf16_t*>(a.XS);
+    // ---- store xs for the tile's central R rows
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int tr = wave * (MB * 32) + mb * 32 + fl;
@@ -230,32 +271,19 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
         bf16_t* row = XS + (seq_row0 + (size_t)(store ? t : 0)) * a.ldxs;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            float cc[2][8];
+            f32x16 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                rb_u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(y[mb][nb][e]), __float_as_uint(y[mb][nb][4 + e]), false, false);
-                rb_u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(y[mb][nb][8 + e]), __float_as_uint(y[mb][nb][12 + e]), false, false);
-                cc[0][e] = __uint_as_float(s0[0]); cc[0][4 + e] = __uint_as_float(s0[1]);
-                cc[1][e] = __uint_as_float(s1[0]); cc[1][4 + e] = __uint_as_float(s1[1]);
-            }
+            for (int i = 0; i < 8; ++i) { v[2 * i] = __uint_as_float(xs_pk[mb][nb][i] << 16); v[2 * i + 1] = __uint_as_float(xs_pk[mb][nb][i] & 0xffff0000u); }
+            float cc[2][8];
+            to_rows(v, cc);
             if (store) {
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch) {
-                    bf16_t* p = row + nb * 32 + ch * 16 + fh * 8;
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = cc[ch][e] * a.out_scale;
-                    if (a.accumulate) {
-                        const uint4 old = *reinterpret_cast<const uint4*>(p);
-                        const uint32_t* u = reinterpret_cast<const uint32_t*>(&old);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
-                    }
                     uint4 o;
                     uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                    *reinterpret_cast<uint4*>(p) = o;
+                    for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(cc[ch][2 * e], cc[ch][2 * e + 1]);       // (exact: the values are bf16 already)
+                    *reinterpret_cast<uint4*>(row + nb * 32 + ch * 16 + fh * 8) = o;
                 }
             }
         }
@@ -269,34 +297,59 @@ static void launch_resblock(const ResBlockArgs& a, hipStream_t stream) {
     resblock_fused_kernel<C><<<(unsigned)(a.nbatch * a.tiles_per_seq), 512, RbCfg<C>::LDS, stream>>>(a);
 }
 
+static int rb_halo(int k, int d0, int d1, int d2) { return ((k - 1) / 2) * (d0 + d1 + d2 + 3); }
+
 extern "C" int fs2_resblock_supported(int C, int k, int d0, int d1, int d2, int dtype) {
     if (dtype != FS2_BF16 || (C != 32 && C != 64) || k < 1 || k > 11 || !(k & 1)) return 0;
     if (d0 < 1 || d1 < 1 || d2 < 1) return 0;
     const int pad2 = (k - 1) / 2;
     if (pad2 * (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) > 32) return 0;                 // a shifted read stays inside the guard rows
-    const int H = pad2 * (d0 + d1 + d2 + 3);
     const int E = C == 32 ? 1024 : 512;
-    return E - 2 * H >= 64 ? 1 : 0;
+    return E - 2 * rb_halo(k, d0, d1, d2) >= 64 ? 1 : 0;
 }
 
-extern "C" int fs2_resblock_fwd(const void* x, long ldx, const void* w1, const void* w2, const float* b1, const float* b2, void* xs,
-                                long ldxs, int accumulate, float out_scale, float slope, int B, int S, int C, int k, int d0, int d1,
-                                int d2, int dtype, hipStream_t stream) {
-    FS2_CHECK_ARG(x && w1 && w2 && b1 && b2 && xs, "resblock_fwd: null pointer");
+static int resblocks_impl(const void* x, long ldx, int nblk, const void* const* w1, const void* const* w2, const float* const* b1,
+                          const float* const* b2, const int* k, void* xs, long ldxs, int accumulate, float out_scale, float slope, int B,
+                          int S, int C, int d0, int d1, int d2, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && xs && nblk >= 1 && nblk <= 3, "resblock_fwd: null pointer / block count");
     FS2_CHECK_ARG(B > 0 && S > 0, "resblock_fwd: bad shape");
-    FS2_CHECK_ARG(fs2_resblock_supported(C, k, d0, d1, d2, dtype), "resblock_fwd: unsupported (C in {32, 64}, odd k <= 11, bf16)");
-    FS2_CHECK_ARG(ldx % 8 == 0 && ldxs % 8 == 0 && (((uintptr_t)x | (uintptr_t)xs | (uintptr_t)w1 | (uintptr_t)w2) & 15) == 0,
-                  "resblock_fwd: rows must be 16-byte addressable");
+    FS2_CHECK_ARG(ldx % 8 == 0 && ldxs % 8 == 0 && (((uintptr_t)x | (uintptr_t)xs) & 15) == 0, "resblock_fwd: rows must be 16-byte addressable");
     FS2_CHECK_ARG(slope > 0.f && slope < 1.f, "resblock_fwd: leaky-ReLU slope in (0, 1)");
-    ResBlockArgs a;
-    a.X = x; a.ldx = ldx; a.W1 = w1; a.W2 = w2; a.B1 = b1; a.B2 = b2; a.XS = xs; a.ldxs = ldxs;
-    a.accumulate = accumulate; a.out_scale = out_scale; a.slope = slope; a.S = S; a.nbatch = B; a.k = k;
+    ResBlockArgs a = {};
+    int H = 0;
+    for (int j = 0; j < nblk; ++j) {
+        FS2_CHECK_ARG(w1[j] && w2[j] && b1[j] && b2[j] && (((uintptr_t)w1[j] | (uintptr_t)w2[j]) & 15) == 0, "resblock_fwd: weights");
+        FS2_CHECK_ARG(fs2_resblock_supported(C, k[j], d0, d1, d2, dtype), "resblock_fwd: unsupported (C in {32, 64}, odd k <= 11, bf16)");
+        a.W1[j] = w1[j]; a.W2[j] = w2[j]; a.B1[j] = b1[j]; a.B2[j] = b2[j]; a.k[j] = k[j];
+        const int h = rb_halo(k[j], d0, d1, d2);
+        H = h > H ? h : H;                               // one tile geometry for all blocks: the widest halo
+    }
+    a.nblk = nblk;
+    a.X = x; a.ldx = ldx; a.XS = xs; a.ldxs = ldxs;
+    a.accumulate = accumulate; a.out_scale = out_scale; a.slope = slope; a.S = S; a.nbatch = B;
     a.d[0] = d0; a.d[1] = d1; a.d[2] = d2;
-    const int H = ((k - 1) / 2) * (d0 + d1 + d2 + 3);
     const int E = C == 32 ? 1024 : 512;
     a.R = E - 2 * H;
     a.tiles_per_seq = fs2_cdiv(S, a.R);
     if (C == 32) launch_resblock<32>(a, stream); else launch_resblock<64>(a, stream);
     FS2_CHECK_LAUNCH("resblock_fwd");
     return FS2_OK;
+}
+
+extern "C" int fs2_resblock_fwd(const void* x, long ldx, const void* w1, const void* w2, const float* b1, const float* b2, void* xs,
+                                long ldxs, int accumulate, float out_scale, float slope, int B, int S, int C, int k, int d0, int d1,
+                                int d2, int dtype, hipStream_t stream) {
+    return resblocks_impl(x, ldx, 1, &w1, &w2, &b1, &b2, &k, xs, ldxs, accumulate, out_scale, slope, B, S, C, d0, d1, d2, dtype, stream);
+}
+
+extern "C" int fs2_resstage_fwd(const void* x, long ldx, const void* w1a, const void* w2a, const float* b1a, const float* b2a, int ka,
+                                const void* w1b, const void* w2b, const float* b1b, const float* b2b, int kb, const void* w1c,
+                                const void* w2c, const float* b1c, const float* b2c, int kc, void* xs, long ldxs, float out_scale,
+                                float slope, int B, int S, int C, int d0, int d1, int d2, int dtype, hipStream_t stream) {
+    const void* w1[3] = {w1a, w1b, w1c};
+    const void* w2[3] = {w2a, w2b, w2c};
+    const float* b1[3] = {b1a, b1b, b1c};
+    const float* b2[3] = {b2a, b2b, b2c};
+    const int k[3] = {ka, kb, kc};
+    return resblocks_impl(x, ldx, 3, w1, w2, b1, b2, k, xs, ldxs, 0, out_scale, slope, B, S, C, d0, d1, d2, dtype, stream);
 }

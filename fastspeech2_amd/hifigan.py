@@ -100,7 +100,8 @@ class Generator(nn.Module):
         self.conv_post = _WNConv((1, c0 // (2 ** self.num_upsamples), 7), c0 // (2 ** self.num_upsamples) * 7)
         self.set_compute_dtype(compute_dtype)
         self._packed = None
-        self.fuse_resblocks = True       # False: every convolution of the narrow stages as its own launch (A/B, parity tests)
+        # True: a narrow stage's three residual blocks in one launch; "block": one launch per block; False: one per convolution (A/B, tests)
+        self.fuse_resblocks = True
         self.stage_probe = None          # a list: _run appends the output rows of conv_pre and of every up-sampling stage (tests)
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
@@ -196,6 +197,21 @@ class Generator(nn.Module):
             S = S * u
             x = y.view(B * S, cout)
             xs = None
+            fz = [W.get(f"rb{i * nk + j}.fused") for j in range(nk)] if self.fuse_resblocks else [None]
+            dils = {self.resblocks[i * nk + j].dilations for j in range(nk)}
+            if nk == 3 and all(f is not None for f in fz) and len(dils) == 1 and self.fuse_resblocks != "block":
+                # the whole stage's residual blocks in ONE launch: x read once, xs written once
+                xs = torch.empty_like(x)
+                ks = [self.resblocks[i * nk + j].kernel_size for j in range(nk)]
+                args = []
+                for j in range(nk):
+                    args += [fz[j][0].data_ptr(), fz[j][1].data_ptr(), fz[j][2].data_ptr(), fz[j][3].data_ptr(), ks[j]]
+                _lib.call("fs2_resstage_fwd", x.data_ptr(), x.stride(0), *args, xs.data_ptr(), xs.stride(0), 1.0 / nk, LRELU_SLOPE,
+                          B, S, x.shape[1], *next(iter(dils)), ops.dt(x), ops._stream())
+                x = xs
+                if self.stage_probe is not None:
+                    self.stage_probe.append((x, S))
+                continue
             for j in range(nk):
                 rb = self.resblocks[i * nk + j]
                 rk = rb.kernel_size

@@ -144,6 +144,19 @@ def resblock_fwd(x, w1, w2, b1, b2, B, S, k, dilations, xs=None, out_scale=1.0, 
     return xs
 
 
+def resstage_fwd(x, blocks, B, S, dilations, out_scale=1.0 / 3, slope=0.1):
+    """the three residual blocks of one up-sampling stage in one launch (fs2_resstage_fwd): blocks = [(w1, w2, b1, b2, k)] x 3;
+    returns xs = out_scale * sum of the blocks' outputs."""
+    xs = torch.empty_like(x)
+    args = []
+    for w1, w2, b1, b2, k in blocks:
+        args += [_p(w1), _p(w2), _p(b1), _p(b2), k]
+    d0, d1, d2 = dilations
+    _lib.call("fs2_resstage_fwd", _p(x), x.stride(0), *args, _p(xs), xs.stride(0), out_scale, slope, B, S, x.shape[1], d0, d1, d2, dt(x),
+              _stream())
+    return xs
+
+
 def conv_gemm_tall(x, wpacked, bias, S, taps, pad, act=ACT_NONE, slope=0.0, res=None, out=None, accumulate=False, out_scale=1.0,
                    tail_ws=None):
     """the 512 x 128 tall-tile kernel by name (fs2_conv_gemm_tall): parity test / A-B tool only - conv_gemm never dispatches to it"""

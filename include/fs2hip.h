@@ -254,6 +254,13 @@ int fs2_resblock_supported(int C, int k, int d0, int d1, int d2, int dtype);
 int fs2_resblock_fwd(const void* x, long ldx, const void* w1, const void* w2, const float* b1, const float* b2, void* xs,
                      long ldxs, int accumulate, float out_scale, float slope, int B, int S, int C, int k, int d0, int d1, int d2,
                      int dtype, fs2_stream_t stream);
+/* models.py:155-160 for a whole up-sampling stage: the three residual blocks (kernel sizes ka / kb / kc, same dilations) of one x
+ * in ONE launch - xs = out_scale * (block_a(x) + block_b(x) + block_c(x)), the running xs rounded to the storage dtype after
+ * every block (as the per-block launches stored it): x is read once from HBM (twice more from L2), xs written once. */
+int fs2_resstage_fwd(const void* x, long ldx, const void* w1a, const void* w2a, const float* b1a, const float* b2a, int ka,
+                     const void* w1b, const void* w2b, const float* b1b, const float* b2b, int kb, const void* w1c,
+                     const void* w2c, const float* b1c, const float* b2c, int kc, void* xs, long ldxs, float out_scale,
+                     float slope, int B, int S, int C, int d0, int d1, int d2, int dtype, fs2_stream_t stream);
 /* stft.py:60-66: xp[b][i] = y[b][reflect(i - P)], i < N + 2P; zero-filled up to row_len. */
 int fs2_reflect_pad(const float* y, float* xp, int B, int N, int P, long row_len, fs2_stream_t stream);
 /* The same for a ragged batch (preprocessor/preprocessor.py:194 over a corpus): row b holds lens[b] samples (row stride ldy,

@@ -1,0 +1,64 @@
+"""Where do the small device copies / elementwise launches of a batch-synthesis step come from?  torch.profiler over a few steps of
+bench.py's synthesis loop, grouped by the Python call site that issued them (rocprofv3 shows ~90 `__amd_rocclr_copyBuffer` launches of
+512 threads per step and ~35 ATen elementwise kernels, 0.5 ms of a 8 ms step)."""
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    args = bench.parse(["--mode", "synth"])
+    dev = torch.device("cuda:0")
+    import math
+    from fastspeech2_amd import synthetic as configs
+    from fastspeech2_amd.synthetic import synthetic_batch, val_phoneme_counts
+    from fastspeech2_amd.model import FastSpeech2
+    from fastspeech2_amd import hifigan, utils
+    pcfg, mcfg = configs.make_configs(dec_layers=4, enc_layers=4)
+    torch.manual_seed(1234)
+    model = FastSpeech2(pcfg, mcfg, compute_dtype="bf16")
+    with torch.no_grad():
+        model.variance_adaptor.duration_predictor.linear_layer.bias.fill_(math.log(8.0))
+    model.to(dev).eval()
+    voc = hifigan.Generator(hifigan.AttrDict(utils.HIFIGAN_V1), compute_dtype="bf16")
+    voc.eval(); voc.remove_weight_norm(); voc.to(dev)
+    counts = val_phoneme_counts()
+    batches = []
+    for gi in range(6):
+        b = synthetic_batch(4321 + gi, 0, 0, src_lens=counts[8 * gi:8 * gi + 8], sort=False)
+        batches.append(([f"u{i}" for i in range(8)], None, b["speakers"].to(dev), b["texts"].to(dev), b["src_lens"].to(dev), b["max_src_len"]))
+
+    def step(i):
+        batch = batches[i % len(batches)]
+        with torch.no_grad():
+            out = model(*batch[2:])
+            return utils.synth_samples(batch, out, voc, mcfg, pcfg, None, write=False)
+
+    for i in range(6):
+        step(i)
+    torch.cuda.synchronize()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+    by = collections.Counter()
+    for e in prof.events():
+        n = e.name
+        if any(s in n for s in ("Memcpy", "memcpy", "copy_", "aten::to", "aten::item", "aten::_local_scalar_dense", "aten::mul", "aten::add",
+                                "aten::contiguous", "aten::clone", "aten::empty_like", "aten::cat", "aten::fill_")):
+            st = [f for f in (e.stack or []) if "fastspeech2_amd" in f or "bench.py" in f or "prof_synth" in f]
+            by[(n, st[0] if st else "?")] += 1
+    for (n, st), c in by.most_common(40):
+        print(f"{c / 3:7.1f} /step  {n:38s} {st}")
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
+
+
+if __name__ == "__main__":
+    main()
