@@ -17,6 +17,10 @@
 //     computed from outside the tile stays inside that margin (it moves inward by one convolution's reach per convolution);
 //   * weights stream L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, source-side swizzle) in groups of up to TG taps through two
 //     slots, the next group in flight while the current one is multiplied; one raw barrier per group.
+// Measured (profiles/r05b-r05d): batch synthesis 9.55 -> 8.13 ms per step with one launch per block, -> 7.47 ms with the three blocks of a
+// stage in one launch (RTF 2.29e-4 -> 1.80e-4); MFMA busy 42 % (C = 64) / 29 % (C = 32).  Requesting the fragments one k-slice ahead
+// through two register sets (order pinned with sched_barrier) was SLOWER (7.47 -> 7.75 ms: 241 registers, the address arithmetic no
+// longer interleaves with the MFMAs); the compiler's own order stays.
 // The first attempt at this fusion (round 1: conv1 -> conv2 pair, weight groups behind barrier PAIRS, register-staged) was 24 %
 // slower than two launches; this one has no staging registers, no per-group barrier pair and keeps y out of LDS altogether.
 #include "fs2_gemm.h"
@@ -207,58 +211,32 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
             if (gi + 1 < ngroups) issue_group(gi + 1);
             const int tap0 = g * TG, nt = min(TG, kj - tap0);
             const unsigned wslot = (unsigned)(K::W_OFF + (gi & 1) * K::SLOT);
-            // fragments of (tap tl, k-slice ks) -> one of two register sets; the set of the NEXT (tap, k-slice) is requested before the
-            // current one is multiplied (the compiler's own order put every read right in front of its MFMA: ~130 cycles of LDS latency
-            // per 4 MFMAs, hidden only by the SIMD's other wave)
-            auto xaddr = [&](int tl, unsigned (&xrow)[MB], unsigned (&xkey)[MB]) {
+            for (int tl = 0; tl < nt; ++tl) {
                 const int shift = (tap0 + tl) * dil - pad;
+                unsigned xrow[MB], xkey[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     const unsigned lr = (unsigned)(GUARD + wave * (MB * 32) + mb * 32 + fl + shift);
                     xrow[mb] = lr * ROWB; xkey[mb] = rb_key<C>(lr);
                 }
-            };
-            auto load_frags = [&](int tl, int ks, const unsigned (&xrow)[MB], const unsigned (&xkey)[MB], rb_u32x4 (&wf)[NB], rb_u32x4 (&xf)[MB]) {
-                const unsigned chunk = (unsigned)(2 * ks + fh);
                 const unsigned wtap = wslot + (unsigned)(tl * K::TAPB);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    wf[nb] = *reinterpret_cast<const rb_u32x4*>(smem + wtap + wrow[nb] + ((chunk ^ wkey[nb]) << 4));
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-                    xf[mb] = *reinterpret_cast<const rb_u32x4*>(smem + xrow[mb] + ((chunk ^ xkey[mb]) << 4));
-            };
-            auto mma = [&](const rb_u32x4 (&wf)[NB], const rb_u32x4 (&xf)[MB]) {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned chunk = (unsigned)(2 * ks + fh);
+                    rb_u32x4 wf[NB], xf[MB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[nb]), __builtin_bit_cast(bf16x8, xf[mb]),
-                                                                              acc[mb][nb], 0, 0, 0);
-            };
-            static_assert(KS % 2 == 0, "two fragment sets alternate over the k-slices");
-            rb_u32x4 wfA[NB], xfA[MB], wfB[NB], xfB[MB];
-            unsigned xrow[MB], xkey[MB], xrow_n[MB], xkey_n[MB];
-            xaddr(0, xrow, xkey);
-            load_frags(0, 0, xrow, xkey, wfA, xfA);
-            for (int tl = 0; tl < nt; ++tl) {
-                const int tln = min(tl + 1, nt - 1);          // (after the last tap: a harmless re-read of its first slice)
-                xaddr(tln, xrow_n, xkey_n);
+                        wf[nb] = *reinterpret_cast<const rb_u32x4*>(smem + wtap + wrow[nb] + ((chunk ^ wkey[nb]) << 4));
 #pragma unroll
-                for (int ks = 0; ks < KS; ks += 2) {
-                    // (sched_barrier pins the order: unpinned, the scheduler sinks every read back to just above its MFMA)
-                    load_frags(tl, ks + 1, xrow, xkey, wfB, xfB);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(wfA, xfA);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (ks + 2 < KS) load_frags(tl, ks + 2, xrow, xkey, wfA, xfA);
-                    else load_frags(tln, 0, xrow_n, xkey_n, wfA, xfA);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma(wfB, xfB);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int mb = 0; mb < MB; ++mb)
+                        xf[mb] = *reinterpret_cast<const rb_u32x4*>(smem + xrow[mb] + ((chunk ^ xkey[mb]) << 4));
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[nb]), __builtin_bit_cast(bf16x8, xf[mb]),
+                                                                                  acc[mb][nb], 0, 0, 0);
                 }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) { xrow[mb] = xrow_n[mb]; xkey[mb] = xkey_n[mb]; }
             }
         }
     };
