@@ -769,7 +769,11 @@ static dim3 bn_geometry(BnArgs& a, int M, int C, int nthreads, int want_blocks, 
 #define BN_WS_ROWS 256             /* slab rows of a workspace >= row groups of any reducing launch (<= BN_*_BLOCKS) */
 // workspace of the reducing launches: [2C reduced sums][BN_WS_ROWS x 2C partial sums]
 extern "C" int fs2_bn_ws_floats(int C) { return C > 0 ? 2 * C + BN_WS_ROWS * 2 * C : 0; }
-static int bn_ws_bind(BnArgs& a, float* ws, int C, dim3 grid) {
+static int bn_ws_bind(BnArgs& a, float* ws, long ws_floats, int C, dim3 grid) {
+    if (ws_floats < (long)fs2_bn_ws_floats(C)) {
+        fs2_set_error("bn: workspace of %ld floats, fs2_bn_ws_floats(%d) = %d needed", ws_floats, C, fs2_bn_ws_floats(C));
+        return FS2_EINVAL;
+    }
     a.sums = ws;
     a.slab = ws + 2 * C;
     if (grid.x > BN_WS_ROWS) { fs2_set_error("bn: launch geometry %u x %u exceeds the workspace", grid.x, grid.y); return FS2_EINVAL; }
@@ -783,14 +787,14 @@ static void bn_slab_sum(const BnArgs& a, dim3 grid, int C, float* acc_dbeta, flo
 
 // stats[0..C) = sum, stats[C..2C) = sum of squared deviations.  `stats` is a workspace of fs2_bn_ws_floats(C) floats whose
 // counter words are zero on entry (zero the whole workspace once, when it is allocated; the kernels leave them zero).
-extern "C" int fs2_bn_stats(const void* x, float* stats, int M, int C, int dtype, hipStream_t stream) {
+extern "C" int fs2_bn_stats(const void* x, float* stats, long ws_floats, int M, int C, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && stats, "bn_stats: null pointer");
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
     a.x = x;
     const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
-    if (int e = bn_ws_bind(a, stats, C, grid)) return e;
+    if (int e = bn_ws_bind(a, stats, ws_floats, C, grid)) return e;
     BN_LAUNCH(0, 1024, grid);
     bn_slab_sum(a, grid, C, nullptr, nullptr, stream);
     if (dtype == FS2_F32) bn_stats_fix_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats, M, C);
@@ -852,15 +856,16 @@ __global__ void bn_fix_finalize_kernel(const T* __restrict__ x, float* __restric
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
     }
 }
-extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                  float* mean_rstd, int M, int C, float eps, float momentum, int dtype, hipStream_t stream) {
+extern "C" int fs2_bn_train_stats(const void* x, float* stats_ws, long ws_floats, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, float* mean_rstd, int M, int C, float eps, float momentum, int dtype,
+                                  hipStream_t stream) {
     FS2_CHECK_ARG(x && stats_ws && mean_rstd, "bn_train_stats: null pointer");
     FS2_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "bn_train_stats: bad shape M=%d C=%d", M, C);
     BnArgs a = {};
     a.x = x;
     const int vec = 4;                   // reducing modes stay at 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_REDUCE_BLOCKS, vec, BN_REDUCE_CBLK);
-    if (int e = bn_ws_bind(a, stats_ws, C, grid)) return e;
+    if (int e = bn_ws_bind(a, stats_ws, ws_floats, C, grid)) return e;
     BN_LAUNCH(0, 1024, grid);
     if (dtype == FS2_F32) bn_fix_finalize_kernel<float><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const float*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum, (int)grid.x);
     else bn_fix_finalize_kernel<bf16_t><<<fs2_cdiv(C, 256), 256, 0, stream>>>((const bf16_t*)x, stats_ws, running_mean, running_var, (long long*)num_batches_tracked, mean_rstd, M, C, eps, momentum, (int)grid.x);
@@ -897,7 +902,7 @@ extern "C" int fs2_bn_apply(const void* x, const float* mean_rstd, const float* 
 //           pass 2: dx = gamma*rstd*(g - sums[c]/M - xhat*sums[C+c]/M)
 // sums (a workspace of fs2_bn_ws_floats(C) floats, counter words zero on entry) receives dbeta (first C) and dgamma (next C).
 extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
-                          float* sums, void* dx, int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev,
+                          float* sums, long ws_floats, void* dx, int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev,
                           int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && dout && mean_rstd && gamma && beta && sums && dx, "bn_bwd: null pointer");
     FS2_CHECK_ARG(C % 4 == 0 && C <= 1024, "bn_bwd: C=%d must be a multiple of 4, <= 1024", C);
@@ -907,7 +912,7 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
     int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
-    if (int e = bn_ws_bind(a, sums, C, grid)) return e;
+    if (int e = bn_ws_bind(a, sums, ws_floats, C, grid)) return e;
     BN_LAUNCH(2, 1024, grid);
     bn_slab_sum(a, grid, C, nullptr, nullptr, stream);
     vec = bn_vec(a, C, dtype);
@@ -920,7 +925,7 @@ extern "C" int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rst
 // the same with the affine gradients accumulated: dgamma_acc / dbeta_acc (parameter-gradient buffers) += the reduced sums.
 // Successive calls (any width-C layer, one stream) may share one workspace.
 extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
-                              float* sums, void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act,
+                              float* sums, long ws_floats, void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act,
                               float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && dout && mean_rstd && gamma && beta && sums && dx && dgamma_acc && dbeta_acc, "bn_bwd_acc: null pointer");
     FS2_CHECK_ARG(C % 4 == 0 && C <= 1024, "bn_bwd_acc: C=%d must be a multiple of 4, <= 1024", C);
@@ -930,7 +935,7 @@ extern "C" int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean
     a.p = p; a.seed = seed; a.seed_dev = seed_dev;
     int vec = 4;                         // reducing pass: 4 channels per thread (see bn_vec)
     dim3 grid = bn_geometry(a, M, C, 1024, BN_BWD1_BLOCKS, vec, BN_REDUCE_CBLK);
-    if (int e = bn_ws_bind(a, sums, C, grid)) return e;
+    if (int e = bn_ws_bind(a, sums, ws_floats, C, grid)) return e;
     BN_LAUNCH(2, 1024, grid);
     bn_slab_sum(a, grid, C, dbeta_acc, dgamma_acc, stream);       // ordered sums + the affine gradients (sum g = dbeta, sum g*xhat = dgamma)
     vec = bn_vec(a, C, dtype);

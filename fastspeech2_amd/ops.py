@@ -349,11 +349,11 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, act, p, seed, eps=1e
     M, C = x.shape
     mean_rstd = torch.empty(2 * C, device=x.device, dtype=torch.float32)
     if ws is not None:
-        _lib.call("fs2_bn_train_stats", _p(x), _p(ws), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(mean_rstd),
+        _lib.call("fs2_bn_train_stats", _p(x), _p(ws), ws.numel(), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(mean_rstd),
                   M, C, eps, momentum, dt(x), _stream())
     else:
         stats = bn_workspace(C, x.device)
-        _lib.call("fs2_bn_stats", _p(x), _p(stats), M, C, dt(x), _stream())
+        _lib.call("fs2_bn_stats", _p(x), _p(stats), stats.numel(), M, C, dt(x), _stream())
         _lib.call("fs2_bn_finalize", _p(stats), _p(running_mean), _p(running_var), _p(mean_rstd), M, C, eps, momentum,
                   _stream())
     out = torch.empty_like(x)
@@ -371,7 +371,7 @@ def bn_bwd_acc(x, dout, mean_rstd, gamma, beta, act, p, seed, ws, dgamma_acc, db
     """BatchNorm backward with the affine gradients accumulated straight into dgamma_acc / dbeta_acc; ws: bn_workspace(C)."""
     M, C = x.shape
     dx = torch.empty_like(x)
-    _lib.call("fs2_bn_bwd_acc", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(ws), _p(dx), _p(dgamma_acc),
+    _lib.call("fs2_bn_bwd_acc", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(ws), ws.numel(), _p(dx), _p(dgamma_acc),
               _p(dbeta_acc), M, C, act, p, seed, _p(seed_dev), dt(x), _stream())
     return dx
 
@@ -380,7 +380,7 @@ def bn_bwd(x, dout, mean_rstd, gamma, beta, act, p, seed, seed_dev=None):
     M, C = x.shape
     sums = bn_workspace(C, x.device)
     dx = torch.empty_like(x)
-    _lib.call("fs2_bn_bwd", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(sums), _p(dx), M, C, act, p, seed,
+    _lib.call("fs2_bn_bwd", _p(x), _p(dout), _p(mean_rstd), _p(gamma), _p(beta), _p(sums), sums.numel(), _p(dx), M, C, act, p, seed,
               _p(seed_dev), dt(x), _stream())
     return dx, sums[C:2 * C], sums[:C]  # dx, dgamma, dbeta
 

@@ -164,14 +164,17 @@ int fs2_ln_bwd_reduce(const float* partial_ws, int C, float* dgamma /*+=*/, floa
 /* ---- BatchNorm1d (+tanh, +dropout) of PostNet: transformer/Layers.py:129-137 ------------------------ */
 /* Column sums are bit-reproducible: every reducing launch stores per-workgroup partial sums in a workspace and a second tiny
  * launch adds them in index order (no float atomics, no device-scope fences).  A BN workspace holds fs2_bn_ws_floats(C)
- * floats (any contents); its first 2C floats receive the sums. */
+ * floats (any contents); its first 2C floats receive the sums.  Every reducing entry point takes the workspace's size in floats
+ * (`ws_floats`) right behind the pointer and refuses one smaller than fs2_bn_ws_floats(C) - rounds 1-3 needed 2C floats, so a caller
+ * built against the old prototype now fails at the call instead of being written out of bounds. */
 int fs2_bn_ws_floats(int C);
-int fs2_bn_stats(const void* x, float* stats /*workspace; [0,2C) = sum | sum of squared deviations*/, int M, int C, int dtype,
-                 fs2_stream_t stream);
+int fs2_bn_stats(const void* x, float* stats /*workspace; [0,2C) = sum | sum of squared deviations*/, long ws_floats, int M, int C,
+                 int dtype, fs2_stream_t stream);
 /* train-mode statistics without housekeeping launches; also updates the running statistics and increments
  * num_batches_tracked (int64, optional) - nn.BatchNorm1d's buffers. */
-int fs2_bn_train_stats(const void* x, float* stats_ws, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                       float* mean_rstd, int M, int C, float eps, float momentum, int dtype, fs2_stream_t stream);
+int fs2_bn_train_stats(const void* x, float* stats_ws, long ws_floats, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float* mean_rstd, int M, int C, float eps, float momentum, int dtype,
+                       fs2_stream_t stream);
 int fs2_bn_finalize(const float* stats, float* running_mean, float* running_var, float* mean_rstd /*2C*/, int M, int C,
                     float eps, float momentum, fs2_stream_t stream);
 /* out = drop(act(BN(x))) + res ; seed_dev (optional, device) is added to every dropout seed so that a replayed
@@ -179,12 +182,12 @@ int fs2_bn_finalize(const float* stats, float* running_mean, float* running_var,
 int fs2_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, const void* res, void* out,
                  int M, int C, int act, float p, uint64_t seed, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 int fs2_bn_bwd(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta,
-               float* sums /*workspace; [0,2C) = dbeta|dgamma*/, void* dx, int M, int C, int act, float p, uint64_t seed,
-               const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
+               float* sums /*workspace; [0,2C) = dbeta|dgamma*/, long ws_floats, void* dx, int M, int C, int act, float p,
+               uint64_t seed, const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 /* the same with dgamma_acc / dbeta_acc (parameter-gradient buffers) += the reduced sums; successive calls on one stream may
  * share one workspace. */
 int fs2_bn_bwd_acc(const void* x, const void* dout, const float* mean_rstd, const float* gamma, const float* beta, float* sums,
-                   void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act, float p, uint64_t seed,
+                   long ws_floats, void* dx, float* dgamma_acc, float* dbeta_acc, int M, int C, int act, float p, uint64_t seed,
                    const uint64_t* seed_dev, int dtype, fs2_stream_t stream);
 
 /* ---- gathers / index kernels ----------------------------------------------------------------------- */

@@ -242,6 +242,22 @@ def test_layernorm_dropout_consistency(dev):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_batchnorm_workspace_size_is_checked(dev):
+    """the reducing BatchNorm entry points grew their workspace from 2C to fs2_bn_ws_floats(C) floats in round 4 under
+    unchanged names; they now take the size and refuse a small buffer instead of writing past it."""
+    from fastspeech2_amd import _lib, ops
+    C, M = 80, 512
+    x = torch.randn(M, C, device=dev)
+    small = torch.zeros(2 * C, device=dev)
+    with pytest.raises(ValueError, match="workspace"):
+        _lib.call("fs2_bn_stats", x.data_ptr(), small.data_ptr(), small.numel(), M, C, ops.F32, ops._stream())
+    ok = ops.bn_workspace(C, dev)
+    assert ok.numel() == _lib.load().fs2_bn_ws_floats(C) > 2 * C
+    _lib.call("fs2_bn_stats", x.data_ptr(), ok.data_ptr(), ok.numel(), M, C, ops.F32, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(ok[:C].cpu(), x.sum(0).cpu(), rtol=1e-4, atol=1e-3)
+
+
 def test_batchnorm(dev, dtype, tol):
     ops = _ops()
     torch.manual_seed(5)
