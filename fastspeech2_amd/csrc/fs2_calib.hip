@@ -6,7 +6,7 @@
 // This kernel is that stream - one wave per SIMD, eight independent accumulators, register operands, nothing else in the loop -
 // run for a few hundred microseconds on every CU; bench.py reports its rate beside the nominal peak (`roofline.mfma_sustained`) so
 // that a reader can tell how much of a kernel's distance to 2.5 PF is the kernel and how much is the clock.  Round 4's ablations of
-// the convolution kernels put "MFMAs + barriers only" at the same place (fs2_gemm_t.hip header).
+// the convolution kernels put "MFMAs + barriers only" at the same place (round 4's tall-tile experiment: DESIGN.md §3, git ff5fda0:fastspeech2_amd/csrc/fs2_gemm_t.hip).
 #include "fs2_common.h"
 
 typedef float calib_f32x16 __attribute__((ext_vector_type(16)));

@@ -149,7 +149,6 @@ __device__ __forceinline__ float fs2_drop_scale(uint64_t seed, uint32_t idx, flo
 #define FS2_GEMM_PERSIST 5
 #define FS2_GEMM_PERSIST_1TAP 6
 #define FS2_GEMM_WIDE_1TAP 7
-#define FS2_GEMM_TALL 8
 #define FS2_GEMM_STREAM_K256 9
 #endif
 static inline int fs2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

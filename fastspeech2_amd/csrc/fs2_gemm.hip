@@ -956,10 +956,6 @@ void fs2_conv_gemm_p_launch(const ConvGemmArgs& a, const int32_t* tile_map, hipS
 // defined in fs2_gemm_s.hip
 bool fs2_conv_gemm_s_ok(const ConvGemmArgs& a, int dtype);
 void fs2_conv_gemm_s_launch(const ConvGemmArgs& a, hipStream_t stream);
-// defined in fs2_gemm_t.hip
-bool fs2_conv_gemm_t_can(const ConvGemmArgs& a, bool has_map, int dtype);
-bool fs2_conv_gemm_t_ok(const ConvGemmArgs& a, bool has_map, int dtype, bool have_tail_ws);
-void fs2_conv_gemm_t_launch(const ConvGemmArgs& a, hipStream_t stream, float* tail_ws);
 struct GemmPick { int variant; bool ring_inact, ks2; };
 static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, bool has_tail_ws = true) {
     const int M = a.M, N = a.N, Cin = a.Cin, taps = a.taps, dil = a.dil, in_act = a.in_act;
@@ -995,8 +991,6 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, b
     // streaming kernel with the weights in registers (fs2_gemm_s.hip): the K = 256 Linear layers and data gradients
     if (!skinny && fs2_conv_gemm_s_ok(a, dtype)) { p.variant = FS2_GEMM_STREAM_K256; return p; }
     if (w_on && !skinny && fs2_conv_gemm_w_ok(a, has_map, dtype)) { p.variant = FS2_GEMM_WIDE_1TAP; return p; }
-    // tall-tile all-consumer kernel (fs2_gemm_t.hip): the large convolutions without lens, when its 512-row tiles fill the chip
-    if (!skinny && fs2_conv_gemm_t_ok(a, has_map, dtype, has_tail_ws)) { p.variant = FS2_GEMM_TALL; return p; }
     p.variant = skinny ? FS2_GEMM_SKINNY : (persist ? (taps == 1 ? FS2_GEMM_PERSIST_1TAP : FS2_GEMM_PERSIST) : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN)));
     return p;
 }
@@ -1041,9 +1035,7 @@ static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* b
     const long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
     const GemmPick pk = conv_gemm_pick(a, dtype, tile_map != nullptr, tail_ws != nullptr);
-    if (pk.variant == FS2_GEMM_TALL) {
-        fs2_conv_gemm_t_launch(a, stream, tail_ws);
-    } else if (pk.variant == FS2_GEMM_STREAM_K256) {
+    if (pk.variant == FS2_GEMM_STREAM_K256) {
         fs2_conv_gemm_s_launch(a, stream);
     } else if (pk.variant == FS2_GEMM_SKINNY) {
         if (Cin == 32) launch_skinny<32>(a, stream);
@@ -1106,23 +1098,6 @@ extern "C" int fs2_conv_gemm_tail(const void* X, long ldx, const void* W, const 
     FS2_CHECK_ARG(!tail_ws || ((uintptr_t)tail_ws & 15) == 0, "conv_gemm_tail: tail_ws must be 16-byte aligned");
     return conv_gemm_impl(X, ldx, W, bias, R, ldr, Y, ldy, lens, tile_map, tail_ws, M, N, Cin, S, taps, dil, pad, act, slope, in_act,
                           in_slope, accumulate, out_scale, dtype, stream);
-}
-
-// The 512 x 128 all-consumer kernel (fs2_gemm_t.hip) by name: the default dispatch does not pick it (measured slower than the
-// 256 x 128 persistent kernel at the bench shapes); the parity test and tools/bench_conv.py reach it here.  bf16, taps 5 or 9,
-// dil 1, Cin % 64 == 0, no lens; FS2_EINVAL for anything else.
-extern "C" int fs2_conv_gemm_tall(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y, long ldy,
-                                  float* tail_ws, int M, int N, int Cin, int S, int taps, int pad, int act, float slope, int accumulate,
-                                  float out_scale, int dtype, hipStream_t stream) {
-    FS2_CHECK_ARG(X && W && Y, "conv_gemm_tall: null pointer");
-    FS2_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && S > 0 && taps > 0 && M % S == 0, "conv_gemm_tall: bad shape");
-    FS2_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && (!tail_ws || ((uintptr_t)tail_ws & 15) == 0) && ldx % 8 == 0, "conv_gemm_tall: alignment");
-    ConvGemmArgs a;
-    conv_gemm_fill(a, X, ldx, W, bias, R, ldr, Y, ldy, nullptr, M, N, Cin, S, taps, 1, pad, act, slope, FS2_ACT_NONE, 0.f, accumulate, out_scale, dtype);
-    FS2_CHECK_ARG(fs2_conv_gemm_t_can(a, false, dtype), "conv_gemm_tall: shape not supported (M=%d N=%d Cin=%d taps=%d)", M, N, Cin, taps);
-    fs2_conv_gemm_t_launch(a, stream, tail_ws);
-    FS2_CHECK_LAUNCH("conv_gemm_tall");
-    return FS2_OK;
 }
 
 // K-split form of fs2_conv_gemm for contractions with few output tiles and a long reduction (the encoder's k=9 data gradient:

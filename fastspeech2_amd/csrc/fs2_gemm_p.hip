@@ -711,9 +711,8 @@ static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream
     conv_gemm_p_kernel<ONE_TAP, WIDE, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
 }
 
-// bytes of tail-split scratch fs2_conv_gemm_tail wants: one f32 tile slab per workgroup of a full-chip launch (512 x 128: the
-// tall kernel's tile, fs2_gemm_t.hip; this file's 256 x 128 slabs use the front half of the buffer)
-extern "C" int fs2_conv_gemm_tail_ws_bytes(void) { return fs2_cu_count() * 512 * 128 * (int)sizeof(float); }
+// bytes of tail-split scratch fs2_conv_gemm_tail wants: one f32 256 x 128 tile slab per workgroup of a full-chip launch
+extern "C" int fs2_conv_gemm_tail_ws_bytes(void) { return fs2_cu_count() * 256 * 128 * (int)sizeof(float); }
 
 // Eligibility of the persistent kernel (pure function of the launch description; shared with fs2_conv_gemm_variant).
 bool fs2_conv_gemm_p_ok(const ConvGemmArgs& a, bool has_map, int dtype, int ks) {

@@ -17,10 +17,15 @@
 //     the other's MFMAs - the first cut, four 64-column waves alone on their SIMDs, paid every epilogue load's latency on the
 //     tile's critical path and was slower than the wide kernel (r04t_bench_w.log);
 //   * the LDS-DMA is issued by TWO loader waves that do nothing else: global stores share vmcnt with loads and may retire out
-//     of order with them, so a wave that both prefetches with counted vmcnt and stores every tile cannot count (fs2_gemm_t.hip
+//     of order with them, so a wave that both prefetches with counted vmcnt and stores every tile cannot count (round 4's tall-tile kernel
 //     drains once per tile; here a tile is too short for that).  One raw barrier per tile.
 // LDS rows are 512 bytes (256 channels); the 32 16-byte chunks of a row are XOR-swizzled with (row & 15), which puts the 16 lanes of
 // every ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) on 16 different 16-byte bank groups.
+// Lengths: with `lens` the epilogue zeroes padded rows, but every 64-row tile is still fetched and multiplied - this kernel takes no tile
+// map (the loaders run three tiles ahead of the consumers on a counted vmcnt; a skip list would have to be shared between them before
+// the first barrier).  The engine passes lens only to batches with >= 10 % wholly padded 256-row tiles (Engine._lens_pays); for those
+// the K = 256 launches (qkv, fc, w_2 data gradient: 0.65 of the 8.4 ms LJSpeech step) do not shrink with the padding, the
+// convolutions and the weight gradients do.
 #include "fs2_gemm.h"
 #include "fs2_gemm_epi.h"
 
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(S_THREADS) conv_gemm_s_kernel(ConvGemmArgs a, 
         const unsigned char* Xb = reinterpret_cast<const unsigned char*>(a.X);
         const unsigned ldx2 = (unsigned)(a.ldx * 2);
         const int hi = lane >> 5, pos = lane & 31;
-        auto issue = [&](int t) {                            // tile t of this workgroup -> buffer t % 3; 16 pieces of 2 rows
+        auto issue = [&](int t) {                            // tile t of this workgroup -> buffer t % S_NBUF (4); 16 pieces of 2 rows
             const int m0 = (stripe + t * stripes) * S_TM;
             const unsigned dst0 = smem_u + (unsigned)((t % S_NBUF) * S_TILE_BYTES);
 #pragma unroll

@@ -594,7 +594,10 @@ class Engine:
         st.counts = torch.empty(2, device=self.device, dtype=torch.float32)
         src_lens32, st.src_masks, src_lens32._fs2_tmap = ops.lens_prep(st.src_lens, B, L, st.counts[0:1])
         hint, self.length_hint = self.length_hint, None     # consumed by this forward
-        src_lens32._fs2_skip = self._skip_fraction(hint[0] if hint else getattr(st.src_lens, "_fs2_host", None), L)
+        if hint is not None and any(h is not None and len(h) != B for h in hint):
+            hint = None                                      # set for another batch (a validation call in between): never applied to this one
+        src_host = hint[0] if (hint and hint[0] is not None) else getattr(st.src_lens, "_fs2_host", None)
+        src_lens32._fs2_skip = self._skip_fraction(src_host, L)
 
         # ---- encoder (transformer/Models.py:73-100)
         n_head = self.tc["encoder_head"]

@@ -157,18 +157,6 @@ def resstage_fwd(x, blocks, B, S, dilations, out_scale=1.0 / 3, slope=0.1):
     return xs
 
 
-def conv_gemm_tall(x, wpacked, bias, S, taps, pad, act=ACT_NONE, slope=0.0, res=None, out=None, accumulate=False, out_scale=1.0,
-                   tail_ws=None):
-    """the 512 x 128 tall-tile kernel by name (fs2_conv_gemm_tall): parity test / A-B tool only - conv_gemm never dispatches to it"""
-    M, Cin = x.shape
-    N = wpacked.shape[0]
-    if out is None:
-        out = torch.empty(M, N, device=x.device, dtype=x.dtype)
-    _lib.call("fs2_conv_gemm_tall", _p(x), x.stride(0), _p(wpacked), _p(bias), _p(res), res.stride(0) if res is not None else 0, _p(out),
-              out.stride(0), _p(tail_ws), M, N, Cin, S, taps, pad, act, slope, int(accumulate), out_scale, dt(x), _stream())
-    return out
-
-
 def tail_workspace(device):
     """scratch for conv_gemm(..., tail_ws=): fs2_conv_gemm_tail_ws_bytes() bytes of f32 (one 256x128 slab per CU).  One per stream
     of contraction launches (launches sharing it must not run concurrently)."""

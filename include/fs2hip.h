@@ -78,12 +78,6 @@ int fs2_conv_gemm_splitk(const void* X, long ldx, const void* Wpacked, const flo
  * iters x 8 MFMAs per wave); *flops receives the FLOPs of the launch.  bench.py times it to report what the matrix pipes SUSTAIN
  * under the chip's power management beside the nominal peak.  sink: one float of device memory (never written in practice). */
 int fs2_mfma_calibrate(int iters, float* sink, double* flops, fs2_stream_t stream);
-/* The 512 x 128 tall-tile kernel (fs2_gemm_t.hip) by name: an experiment kept for its parity test and A/B tool - the default
- * dispatch does not pick it (round 4: slower than the 256 x 128 persistent kernel at every shape of the model).  bf16, taps 5 or 9,
- * dil 1, Cin % 64 == 0, no lens, >= one tile per CU; FS2_EINVAL otherwise.  tail_ws: fs2_conv_gemm_tail_ws_bytes() or NULL. */
-int fs2_conv_gemm_tall(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Y, long ldy,
-                       float* tail_ws, int M, int N, int Cin, int S, int taps, int pad, int act, float slope, int accumulate,
-                       float out_scale, int dtype, fs2_stream_t stream);
 /* Which kernel fs2_conv_gemm dispatches a launch description to: a pure function (no state) - a measurement aid that
  * lets bench.py attribute HIP-event durations to the kernel names rocprofv3 reports.  has_lens / has_map: whether
  * lens / tile_map would be non-NULL; ldr = 0 without a residual operand. */
@@ -94,8 +88,8 @@ int fs2_conv_gemm_tall(const void* X, long ldx, const void* Wpacked, const float
 #define FS2_GEMM_PERSIST 5 /* conv_gemm_p_kernel<false>: persistent 256x128 convolution (taps >= 3), MFMA-bound */
 #define FS2_GEMM_PERSIST_1TAP 6 /* conv_gemm_p_kernel<true>: the same kernel for taps == 1 (Linear / k=1 conv): HBM-bound at K <= 1024 */
 #define FS2_GEMM_WIDE_1TAP 7 /* conv_gemm_w_kernel: persistent 256x256 tiles, every wave loads and multiplies (taps == 1, N % 256 == 0) */
-#define FS2_GEMM_TALL 8    /* conv_gemm_t_kernel: persistent 512x128 tiles, eight self-loading consumer waves - never returned by the
-                              shipped dispatch (see fs2_conv_gemm_tall) */
+/* (8 was round 4's 512x128 tall-tile kernel: measured slower at every shape of the model and removed from the library in round 5;
+ *  git history: fastspeech2_amd/csrc/fs2_gemm_t.hip at ff5fda0) */
 #define FS2_GEMM_STREAM_K256 9 /* conv_gemm_s_kernel: one tap, K = 256, N % 256 == 0 - weights in registers, X streamed through LDS (HBM-bound) */
 int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens, int has_map, int M, int N, int Cin, int S, int taps,
                           int dil, int in_act, float in_slope, int dtype);

@@ -124,55 +124,6 @@ def test_contraction_forward_and_dgrad_production_shapes(dev, dtype, name, Cin, 
             assert_rounding_only(yq, ref_l[:Mq], dtype, (name, "fwd tail sweep", nb))
 
 
-@pytest.mark.parametrize("name,Cin,Cout,k", [("ffn w_1 k9", 256, 1024, 9), ("postnet k5", 512, 512, 5), ("k9 C512", 512, 512, 9)])
-def test_tall_tile_kernel_without_lens(dev, name, Cin, Cout, k):
-    """conv_gemm_t_kernel (fs2_gemm_t.hip: 512 x 128 tiles, eight self-loading consumer waves, half-chunk K loop unrolled over a
-    periodic DMA schedule) - round 4's answer to "port the all-consumer structure to the convolution kernel".  It is NOT on the
-    default dispatch (measured slower than the 256 x 128 persistent kernel, profiles/r04j_tall_ablation.log); fs2_conv_gemm_tall
-    reaches it by name.  Every batch size below changes the tile count (whole rounds, 2- / 4-way tail parts, a last M-tile with rows
-    beyond M), sequences end inside tiles (tap masks at both ends of every sequence), and the epilogue variants are the ones the
-    engine uses: bias + ReLU, residual add, ReLU gate, accumulate + scale.  Elementwise against the exact-product reference,
-    rounding only."""
-    ops = _ops()
-    S, dtype = 925, torch.bfloat16
-    g = torch.Generator().manual_seed(sum(ord(c) for c in name) + 1)
-    pad = (k - 1) // 2
-    x = torch.randn(B * S, Cin, generator=g).to(dev).to(dtype)
-    w = (torch.randn(Cout, k, Cin, generator=g) / math.sqrt(Cin * k)).to(dev)
-    bias = torch.randn(Cout, generator=g).to(dev)
-    wf, wd = ops.pack_weight(w, dtype)
-    ref = conv_ref_gpu(x, wf, bias, S, pad)
-    tws = ops.tail_workspace(dev).fill_(float("nan"))
-    seen = 0
-    for nb in (48, 45, 41, 37, 30, 24, 19):
-        Mq = nb * S
-        if ((Mq + 511) // 512) * ((Cout + 127) // 128) < torch.cuda.get_device_properties(dev).multi_processor_count:
-            with pytest.raises(ValueError):                                  # fewer tiles than CUs: refused, not mis-run
-                ops.conv_gemm_tall(x[:Mq], wf, bias, S, k, pad, act=ops.ACT_RELU, tail_ws=tws)
-            continue
-        seen += 1
-        for tail in (tws, None):
-            y = ops.conv_gemm_tall(x[:Mq], wf, bias, S, k, pad, act=ops.ACT_RELU, tail_ws=tail)
-            assert_rounding_only(y, torch.relu(ref[:Mq]), dtype, (name, "fwd", nb, tail is not None))
-    assert seen >= 2
-    # data gradient forms (tap-flipped pack) at the full batch: residual add, ReLU gate, accumulate with scale
-    dy = torch.randn(B * S, Cout, generator=g).to(dev).to(dtype)
-    res = torch.randn(B * S, Cin, generator=g).to(dev).to(dtype)
-    if ((B * S + 511) // 512) * ((Cin + 127) // 128) >= torch.cuda.get_device_properties(dev).multi_processor_count:
-        dref = conv_ref_gpu(dy, wd, None, S, (k - 1) - pad)
-        dx = ops.conv_gemm_tall(dy, wd, None, S, k, (k - 1) - pad, res=res, tail_ws=tws)
-        assert_rounding_only(dx, dref + res.double(), dtype, (name, "dgrad+res"))
-        dx = ops.conv_gemm_tall(dy, wd, None, S, k, (k - 1) - pad, act=ops.ACT_GATE, res=res, tail_ws=tws)
-        assert_rounding_only(dx, torch.where(res.double() > 0, dref, torch.zeros_like(dref)), dtype, (name, "dgrad gate"))
-    acc0 = torch.randn(B * S, Cout, generator=g).to(dev).to(dtype)
-    out = acc0.clone()
-    ops.conv_gemm_tall(x, wf, bias, S, k, pad, out=out, accumulate=True, out_scale=0.5, tail_ws=tws)
-    assert_rounding_only(out, acc0.double() + 0.5 * ref, dtype, (name, "accumulate"))
-    # and the default dispatch stays on the 256 x 128 persistent kernel for this launch
-    from fastspeech2_amd import _lib
-    assert _lib.load().fs2_conv_gemm_variant(Cin, Cout, 0, 0, 0, B * S, Cout, Cin, S, k, 1, 0, 0.0, 1) == 5
-
-
 @pytest.mark.parametrize("name,N,S,Bq", [("qkv", 768, 925, 48), ("fc", 256, 925, 48), ("w_2 dgrad", 1024, 925, 48), ("N512 short", 512, 333, 40),
                                          ("fc 30 seqs", 256, 925, 30), ("qkv ragged tail", 768, 131, 77)])
 def test_streaming_k256_kernel_epilogues_and_edges(dev, name, N, S, Bq):

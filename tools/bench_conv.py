@@ -31,8 +31,6 @@ for name, K, N, taps, res, act, use_lens in SHAPES:
     r = torch.randn(M, N, device=dev).to(torch.bfloat16) if res else None
     l = lens if use_lens else None
     f = lambda: ops.conv_gemm(x, w, bias, S, taps=taps, pad=(taps - 1) // 2, lens=l, res=r, act=act, tmap=tmap if use_lens else None, tail_ws=tws)
-    if os.environ.get("BENCH_TALL") and not use_lens and taps in (5, 9) and K % 64 == 0 and ((M + 511) // 512) * ((N + 127) // 128) >= 256:
-        f = lambda: ops.conv_gemm_tall(x, w, bias, S, taps, (taps - 1) // 2, act=act, res=r, tail_ws=tws)      # the 512 x 128 kernel by name
     for _ in range(5):
         f()
     torch.cuda.synchronize()
