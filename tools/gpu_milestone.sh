@@ -2,7 +2,7 @@
 # Milestone evidence in one call: parity tests, full bench line (roofline + cpu baseline + fp32), synthesis bench, rocprofv3
 # kernel traces (side stream on = what the bench runs; off = every kernel alone on the device), PMC HBM-traffic passes and
 # two PMC passes for the MFMA / LDS picture of every kernel.
-TAG=${1:-r04z}
+TAG=${1:-r05m}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 # (1) HBM traffic of the contraction kernels FIRST: bench.py refuses a PMC file that was measured on other kernel sources
