@@ -10,17 +10,20 @@
 //   * the running sum y lives in fp32 REGISTERS of the wave that owns the rows (MFMA accumulators, transposed: D[cout][row], so a
 //     lane owns a row and, after v_permlane32_swap, runs of 8 consecutive channels) - the residual add is the accumulator's
 //     initial value, and y is never rounded between the three pairs;
-//   * what a convolution READS (lrelu(y) resp. t) is written as bf16 into ONE LDS tile [GUARD + E + GUARD rows][C], 16-byte chunks
-//     XOR-swizzled per row so that ds_read_b128 by 16 consecutive rows is conflict-free; a tap is a row shift of the fragment address;
+//   * what a convolution READS (lrelu(y) resp. t) is written as bf16 into ONE LDS tile [GUARD + E + GUARD rows][C + 8] (rows padded
+//     by one 16-byte chunk: ds_read_b128 by 16 consecutive rows is conflict-free); a tap is a row shift of the fragment address;
 //     rows outside the utterance are written as zeros (= the reference's zero padding of every convolution's input);
 //   * halo by recomputation: the tile covers H = (k-1)/2 * (d0 + d1 + d2 + 3) more rows on each side than it outputs; whatever is
 //     computed from outside the tile stays inside that margin (it moves inward by one convolution's reach per convolution);
-//   * weights stream L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, source-side swizzle) in groups of up to TG taps through two
-//     slots, the next group in flight while the current one is multiplied; one raw barrier per group.
-// Measured (profiles/r05b-r05d): batch synthesis 9.55 -> 8.13 ms per step with one launch per block, -> 7.47 ms with the three blocks of a
-// stage in one launch (RTF 2.29e-4 -> 1.80e-4); MFMA busy 42 % (C = 64) / 29 % (C = 32).  Requesting the fragments one k-slice ahead
-// through two register sets (order pinned with sched_barrier) was SLOWER (7.47 -> 7.75 ms: 241 registers, the address arithmetic no
-// longer interleaves with the MFMAs); the compiler's own order stays.
+//   * weights stream L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, source-side swizzle) in groups (RbCfg) through a ring of 2 - 4
+//     slots with all but one slot in flight while the current group is multiplied; one raw barrier per group.
+// Measured (profiles/r05b-r05j): batch synthesis 9.55 -> 8.13 ms per step with one launch per block, -> 7.47 ms with the three blocks of a
+// stage in one launch (RTF 2.29e-4 -> 1.80e-4); MFMA busy 39 % (C = 64) / 33 % (C = 32), 5 - 9 VALU per MFMA - most of them the
+// epilogues (leaky-ReLU, pack, store of every convolution's output: a k = 3 convolution at C = 32 is 24 MFMAs and 64 outputs per lane).
+// Tried on top and measured neutral or worse: fragments requested one k-slice ahead through two register sets (7.47 -> 7.75 ms: 241
+// registers), a 4-deep weight ring with three groups in flight instead of one (no change: the stream is not the limiter), padded
+// rows + precomputed fragment addresses (LDS bank conflicts 10-15 % -> 0, VALU per MFMA -1, time unchanged: kept, it is the simpler
+// addressing).
 // The first attempt at this fusion (round 1: conv1 -> conv2 pair, weight groups behind barrier PAIRS, register-staged) was 24 %
 // slower than two launches; this one has no staging registers, no per-group barrier pair and keeps y out of LDS altogether.
 #include "fs2_gemm.h"
@@ -40,30 +43,50 @@ struct ResBlockArgs {
 };
 
 template <int C> struct RbCfg {
-    static constexpr int E = C == 32 ? 1024 : 512;          // tile rows (8 waves x MB x 32)
-    static constexpr int GUARD = 32;                         // rows in front of / behind the tile a shifted read may touch (|shift| <= 25)
+    static constexpr int E = C == 32 ? 1024 : (C == 64 ? 512 : 256);      // tile rows (8 waves x MB x 32): the LDS left beside the weight slots
+    static constexpr int GUARD = 26;                         // rows in front of / behind the tile a shifted read may touch (|shift| <= 25)
+    // activation rows are PADDED by one 16-byte chunk instead of XOR-swizzled: the row stride is an odd number of chunks, so the 16
+    // rows of a ds_read_b128 lane group land on 16 different 16-byte slots, and a fragment address is base(row) + tap shift (a scalar)
+    // + chunk (an immediate) - the XOR form cost 2-3 VALU per read next to every MFMA (PMC r05i: 6.4 - 10.3 VALU per MFMA, 33 - 38 %
+    // MFMA busy: issue-bound)
+    static constexpr int STRIDE = C * 2 + 16;
     static constexpr int MB = E / 256, NB = C / 32, KS = C / 16, CPR = C / 8;
     static constexpr int ROWB = C * 2;
-    static constexpr int TG = C == 32 ? 11 : 4;              // taps per weight group
     static constexpr int TAPB = C * C * 2;                   // bytes of one tap's weights
-    static constexpr int ACT_BYTES = (E + 2 * GUARD) * ROWB;
-    static constexpr int W_OFF = ACT_BYTES, SLOT = TG * TAPB;
-    static constexpr int BIAS_OFF = W_OFF + 2 * SLOT;
+    // A weight GROUP (one ring slot, one barrier) = TG taps x 1 / KP of the reduction: C = 32 a whole convolution (<= 11 taps, 22 KB),
+    // C = 64 two taps (16 KB), C = 128 half a tap (channels 64 kp .. + 64 of all 128 couts: 16 KB).  NSLOT slots, NSLOT - 1 groups in
+    // flight: the L2 -> LDS stream is latency-bound (~2 us issue -> landed), so what counts is bytes in flight per CU - the first
+    // C = 128 cut (whole taps, 2 slots, one group in flight) ran 2.7 us per tap for 1 us of MFMAs (profiles/r05g_kernel_trace_synth.md).
+    static constexpr int TG = C == 32 ? 11 : (C == 64 ? 2 : 1);
+    static constexpr int KP = C == 128 ? 2 : 1;
+    static constexpr int NSLOT = C == 32 ? 2 : 4;
+    static constexpr int KSG = KS / KP;                      // k-slices per group
+    static constexpr int WROWB = ROWB / KP;                  // bytes of a cout's row inside a slot (C = 128: 128)
+    static constexpr int SLOT = TG * TAPB / KP;
+    static constexpr int PPG = SLOT / 1024;                  // 1 KiB DMA pieces of a full group (22 / 16 / 16)
+    static constexpr int PW = C == 32 ? 0 : PPG / 8;         // pieces per wave and group when uniform (C >= 64: 2); 0 = counted by vmcnt(0)
+    static constexpr int ACT_BYTES = ((E + 2 * GUARD) * STRIDE + 1023) / 1024 * 1024;
+    static constexpr int W_OFF = ACT_BYTES;
+    static constexpr int BIAS_OFF = W_OFF + NSLOT * SLOT;
     static constexpr int LDS = BIAS_OFF + 18 * C * 4;
-    static constexpr int PPT = TAPB / 1024;                  // 1 KiB DMA pieces per tap (2 / 8)
 };
 // swizzle key of LDS row r: chunk c is stored at chunk c ^ key (16 consecutive rows x one chunk -> 16 distinct 16-byte slots of the
-// 256-byte bank window: 4 rows per window at C = 32, 2 at C = 64)
-template <int C> __device__ __forceinline__ unsigned rb_key(unsigned r) { return C == 32 ? ((r >> 2) & 3u) : ((r >> 1) & 7u); }
+// 256-byte bank window: 4 rows per window at C = 32, 2 at C = 64, 1 at C = 128)
+template <int C> __device__ __forceinline__ unsigned rb_key(unsigned r) {
+    return C == 32 ? ((r >> 2) & 3u) : (C == 64 ? ((r >> 1) & 7u) : (r & 15u));      // (C = 128: a row IS a bank window)
+}
+// ... and of a cout's row inside a weight slot (C = 128: half rows of 128 bytes, as C = 64)
+template <int C> __device__ __forceinline__ unsigned rb_wkey(unsigned r) { return C == 32 ? ((r >> 2) & 3u) : ((r >> 1) & 7u); }
 
 // raw barrier with this wave's LDS stores (and DMA pieces) retired first; the memory clobber keeps the compiler's LDS accesses on their side
 __device__ __forceinline__ void rb_barrier_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N> __device__ __forceinline__ void rb_barrier_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void rb_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int C>
 __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) {
     typedef RbCfg<C> K;
-    constexpr int E = K::E, GUARD = K::GUARD, MB = K::MB, NB = K::NB, KS = K::KS, ROWB = K::ROWB, TG = K::TG;
+    constexpr int E = K::E, GUARD = K::GUARD, MB = K::MB, NB = K::NB, STRIDE = K::STRIDE, TG = K::TG, KP = K::KP, NSLOT = K::NSLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, fl = lane & 31, fh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,32 +97,38 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
     const int H = (E - a.R) >> 1;
     const int t_first = tile * a.R - H;                      // utterance row of tile row 0
     const size_t seq_row0 = (size_t)seq * a.S;
-    // ---- weight stream over all blocks: group gi -> slot gi & 1.  Block j: convolution c = 2m (conv1 of pair m) / 2m + 1 (conv2), each
-    // in gpc_j = ceil(k_j / TG) groups of <= TG taps
+    // ---- weight stream over all blocks: group gi -> slot gi % NSLOT.  Block j: convolution c = 2m (conv1 of pair m) / 2m + 1 (conv2), each
+    // in gpc_j = ceil(k_j / TG) * KP groups
     int gpc[3], gstart[4];
     gstart[0] = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { gpc[j] = j < a.nblk ? (a.k[j] + TG - 1) / TG : 0; gstart[j + 1] = gstart[j] + 6 * gpc[j]; }
+    for (int j = 0; j < 3; ++j) { gpc[j] = j < a.nblk ? ((a.k[j] + TG - 1) / TG) * KP : 0; gstart[j + 1] = gstart[j] + 6 * gpc[j]; }
     const int ngroups = gstart[3];
     auto issue_group = [&](int gi) {
         const int j = gi >= gstart[2] ? 2 : (gi >= gstart[1] ? 1 : 0);
         const int kj = a.k[j], gl = gi - gstart[j];
         const int c = gl / gpc[j], g = gl - c * gpc[j];
-        const int tap0 = g * TG, nt = min(TG, kj - tap0);
+        const int tap0 = (g / KP) * TG, kp = g % KP, nt = min(TG, kj - tap0);
         const unsigned char* wbase = reinterpret_cast<const unsigned char*>((c & 1) ? a.W2[j] : a.W1[j]) + (size_t)(c >> 1) * C * kj * C * 2;
-        const unsigned slot = smem_u + K::W_OFF + (unsigned)((gi & 1) * K::SLOT);
-        const int npieces = nt * K::PPT;
+        const unsigned slot = smem_u + K::W_OFF + (unsigned)((gi % NSLOT) * K::SLOT);
+        // a 1 KiB piece = RPP couts of one tap (rows of WROWB bytes); lane -> (cout, LDS chunk position); the position holds the global
+        // chunk kp * chunks-per-part + (pos ^ key(cout)).  C >= 64: every wave issues exactly PW pieces per group (a group of fewer
+        // taps re-fetches its last tap into the unused part of the slot: the count a wave waits with stays a compile-time constant)
+        constexpr int RPP = 1024 / K::WROWB, CPP = K::WROWB / 16, PPT = K::TAPB / KP / 1024;
+        const int npieces = K::PW ? K::PPG : nt * PPT;
         for (int q = wave; q < npieces; q += 8) {
-            const int tl = q / K::PPT, p = q - tl * K::PPT;
-            // piece p of a tap = C / PPT couts; lane -> (cout, LDS chunk position); the position holds global chunk pos ^ key(cout)
-            const int cout = p * (C / K::PPT) + lane / K::CPR;
-            const unsigned pos = (unsigned)(lane % K::CPR);
-            const unsigned gch = pos ^ rb_key<C>((unsigned)cout);
-            const unsigned voff = (unsigned)(((cout * kj + tap0 + tl) * C) * 2) + (gch << 4);
-            glds16_sbase(voff, wbase, __builtin_amdgcn_readfirstlane(slot + (unsigned)(tl * K::TAPB + p * 1024)));
+            const int tl = q / PPT, p = q - tl * PPT;
+            const int tsrc = min(tl, nt - 1);
+            const int cout = p * RPP + lane / CPP;
+            const unsigned pos = (unsigned)(lane % CPP);
+            const unsigned gch = (unsigned)(kp * CPP) + (pos ^ rb_wkey<C>((unsigned)cout));
+            const unsigned voff = (unsigned)(((cout * kj + tap0 + tsrc) * C) * 2) + (gch << 4);
+            glds16_sbase(voff, wbase, __builtin_amdgcn_readfirstlane(slot + (unsigned)(tl * (K::TAPB / KP) + p * 1024)));
         }
     };
-    issue_group(0);
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i)
+        if (i < ngroups) issue_group(i);
     for (int i = tid; i < a.nblk * 6 * C; i += 512) {
         const int j = i / (6 * C), r = i - j * 6 * C, c = r / C, n = r - c * C;
         bias_s[i] = ((c & 1) ? a.B2[j] : a.B1[j])[(c >> 1) * C + n];
@@ -144,7 +173,7 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const unsigned lr = (unsigned)(GUARD + wave * (MB * 32) + mb * 32 + fl);
-            const unsigned rowaddr = lr * ROWB, key = rb_key<C>(lr);
+            const unsigned rowaddr = lr * STRIDE;
             const bool live = (in_seq >> mb) & 1u;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -161,7 +190,7 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
                         ou[e] = live ? pack_bf16x2(lo, hi) : 0u;
                     }
                     const unsigned chunk = (unsigned)(nb * 4 + ch * 2 + fh);
-                    *reinterpret_cast<uint4*>(smem + rowaddr + ((chunk ^ key) << 4)) = o;
+                    *reinterpret_cast<uint4*>(smem + rowaddr + (chunk << 4)) = o;
                 }
             }
         }
@@ -185,9 +214,16 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) xs_pk[mb][nb][i] = 0u;
     }
-    unsigned wkey[NB], wrow[NB];
+    // loop-invariant parts of the fragment addresses: weights (XOR-swizzled slot image: one address per cout block and k-slice) and this
+    // lane's activation rows (padded rows: one base per row block; tap shift and k-slice come in as a scalar and an immediate)
+    unsigned wa[NB][K::KSG], xbase[MB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { wrow[nb] = (unsigned)((nb * 32 + fl) * ROWB); wkey[nb] = rb_key<C>((unsigned)(nb * 32 + fl)); }
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < K::KSG; ++ks)
+            wa[nb][ks] = (unsigned)((nb * 32 + fl) * K::WROWB) + ((((unsigned)(2 * ks + fh)) ^ rb_wkey<C>((unsigned)(nb * 32 + fl))) << 4);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) xbase[mb] = (unsigned)((GUARD + wave * (MB * 32) + mb * 32 + fl) * STRIDE + fh * 16);
     int gi = 0;
     // the groups of convolution c of block j multiplied into `acc` (y for conv2: the residual is already in it; t_acc for conv1)
     auto run_conv = [&](f32x16 (&acc)[MB][NB], int j, int c, bool add_bias) {
@@ -206,30 +242,32 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
                 }
             }
         for (int g = 0; g < gpc[j]; ++g, ++gi) {
-            rb_barrier_all();                  // my pieces of group gi landed (nothing younger in flight), my tile rows stored; then:
-                                               // group gi + the activation tile visible to all, slot (gi + 1) & 1 free
-            if (gi + 1 < ngroups) issue_group(gi + 1);
-            const int tap0 = g * TG, nt = min(TG, kj - tap0);
-            const unsigned wslot = (unsigned)(K::W_OFF + (gi & 1) * K::SLOT);
+            // my pieces of group gi have landed (only the NSLOT - 2 groups behind it may still be in flight) and my tile rows are stored;
+            // then: group gi + the activation tile visible to all, slot (gi - 1) % NSLOT free -> group gi + NSLOT - 1 goes there
+            if (K::PW == 0) rb_barrier_all();
+            else {
+                const int younger = min(NSLOT - 2, ngroups - 1 - gi);
+                if (younger >= 2) rb_barrier_vm<2 * (K::PW ? K::PW : 1)>();
+                else if (younger == 1) rb_barrier_vm<(K::PW ? K::PW : 1)>();
+                else rb_barrier_all();
+            }
+            if (gi + NSLOT - 1 < ngroups) issue_group(gi + NSLOT - 1);
+            const int tap0 = (g / KP) * TG, kp = g % KP, nt = min(TG, kj - tap0);
+            const unsigned wslot = (unsigned)(K::W_OFF + (gi % NSLOT) * K::SLOT);
             for (int tl = 0; tl < nt; ++tl) {
                 const int shift = (tap0 + tl) * dil - pad;
-                unsigned xrow[MB], xkey[MB];
+                const int xoff = shift * STRIDE + kp * (K::KSG * 32);                        // (scalar)
+                const unsigned woff = wslot + (unsigned)(tl * (K::TAPB / KP));             // (scalar)
+                const unsigned char* xp[MB];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const unsigned lr = (unsigned)(GUARD + wave * (MB * 32) + mb * 32 + fl + shift);
-                    xrow[mb] = lr * ROWB; xkey[mb] = rb_key<C>(lr);
-                }
-                const unsigned wtap = wslot + (unsigned)(tl * K::TAPB);
+                for (int mb = 0; mb < MB; ++mb) xp[mb] = smem + (int)xbase[mb] + xoff;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const unsigned chunk = (unsigned)(2 * ks + fh);
+                for (int ks = 0; ks < K::KSG; ++ks) {
                     rb_u32x4 wf[NB], xf[MB];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        wf[nb] = *reinterpret_cast<const rb_u32x4*>(smem + wtap + wrow[nb] + ((chunk ^ wkey[nb]) << 4));
+                    for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const rb_u32x4*>(smem + woff + wa[nb][ks]);
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        xf[mb] = *reinterpret_cast<const rb_u32x4*>(smem + xrow[mb] + ((chunk ^ xkey[mb]) << 4));
+                    for (int mb = 0; mb < MB; ++mb) xf[mb] = *reinterpret_cast<const rb_u32x4*>(xp[mb] + ks * 32);
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -304,6 +342,10 @@ static void launch_resblock(const ResBlockArgs& a, hipStream_t stream) {
 static int rb_halo(int k, int d0, int d1, int d2) { return ((k - 1) / 2) * (d0 + d1 + d2 + 3); }
 
 extern "C" int fs2_resblock_supported(int C, int k, int d0, int d1, int d2, int dtype) {
+    // C = 128 has a configuration above (256-row tiles, half-tap weight groups) and was measured: parity green, 35 % MFMA busy, and NO
+    // faster than the chain of single convolutions (stage 1 of HiFi-GAN V1: 2.8 vs 2.4 ms isolated, the batch-synthesis step 7.57 vs
+    // 7.59 ms - profiles/r05g-r05j): 256-row tiles pay 10 / 39 / 88 % halo recomputation at k = 3 / 7 / 11 and stream 32 KB of weights
+    // per tap for 256 rows.  Not instantiated.
     if (dtype != FS2_BF16 || (C != 32 && C != 64) || k < 1 || k > 11 || !(k & 1)) return 0;
     if (d0 < 1 || d1 < 1 || d2 < 1) return 0;
     const int pad2 = (k - 1) / 2;
@@ -335,7 +377,8 @@ static int resblocks_impl(const void* x, long ldx, int nblk, const void* const* 
     const int E = C == 32 ? 1024 : 512;
     a.R = E - 2 * H;
     a.tiles_per_seq = fs2_cdiv(S, a.R);
-    if (C == 32) launch_resblock<32>(a, stream); else launch_resblock<64>(a, stream);
+    if (C == 32) launch_resblock<32>(a, stream);
+    else launch_resblock<64>(a, stream);
     FS2_CHECK_LAUNCH("resblock_fwd");
     return FS2_OK;
 }
