@@ -311,7 +311,8 @@ def synth_cpu_baseline(args, lens8, threads):
 
 SYNTH_NAMES = {1: "conv_gemm_kernel", 2: "conv_gemm_dma_kernel", 3: "conv_gemm_ring_kernel", 4: "conv_skinny_kernel",
                5: "conv_gemm_p_kernel<false> (taps >= 3)", 6: "conv_gemm_p_kernel<true> (taps == 1)", 7: "conv_gemm_w_kernel (taps == 1, N % 256 == 0)",
-               9: "conv_gemm_s_kernel (taps == 1, K == 256: weights in registers)"}
+               9: "conv_gemm_s_kernel (taps == 1, K == 256: weights in registers)",
+               10: "resblock_fused_kernel (HiFi-GAN C = 32 / 64: a stage's three residual blocks in one launch)"}
 
 
 def synth_measure(args, device, rank, world, steps, warmup, want_roofline):

@@ -206,8 +206,15 @@ class Generator(nn.Module):
                 args = []
                 for j in range(nk):
                     args += [fz[j][0].data_ptr(), fz[j][1].data_ptr(), fz[j][2].data_ptr(), fz[j][3].data_ptr(), ks[j]]
+                if ops.PROFILE is not None:          # bench.py's roofline replay: HIP events around the launch, algorithmic FLOPs
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 _lib.call("fs2_resstage_fwd", x.data_ptr(), x.stride(0), *args, xs.data_ptr(), xs.stride(0), 1.0 / nk, LRELU_SLOPE,
                           B, S, x.shape[1], *next(iter(dils)), ops.dt(x), ops._stream())
+                if ops.PROFILE is not None:
+                    e1.record()
+                    C_ = x.shape[1]
+                    ops.PROFILE.setdefault("conv_gemm", []).append((2.0 * B * S * C_ * C_ * sum(ks) * 6, e0, e1, 10, False, S))
                 x = xs
                 if self.stage_probe is not None:
                     self.stage_probe.append((x, S))
