@@ -704,6 +704,38 @@ def main():
                                               "how": "bare v_mfma_f32_32x32x16_bf16 stream, one wave per SIMD on every CU, non-zero operands, median of 3"}
             except Exception as e:  # a measurement aid: never fails the line
                 print(f"[bench] mfma calibration failed ({type(e).__name__}: {e})", file=sys.stderr)
+            # ... and what THIS box's memory side streams (boxes differ by ~10 % at equal or higher MFMA rates):
+            # an HBM copy (1 GiB read + 1 GiB written, beyond the 256 MB Infinity Cache) and the L2 -> LDS-DMA operand path
+            try:
+                import ctypes
+                src = torch.empty(1 << 30, device=device, dtype=torch.uint8).fill_(3)
+                dst = torch.empty_like(src)
+                ts = []
+                for _ in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops._lib.call("fs2_hbm_calibrate", src.data_ptr(), dst.data_ptr(), src.numel(), ops._stream())
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                t = sorted(ts[1:])[1]
+                roofline["hbm_copy"] = {"tb_per_s": round(2 * src.numel() / (t * 1e-3) / 1e12, 3), "frac_of_8tb_peak": round(2 * src.numel() / (t * 1e-3) / 8e12, 4),
+                                        "how": "16-byte-per-lane copy, 1 GiB read + 1 GiB written, median of 3"}
+                by = ctypes.c_double(0.0)
+                ts = []
+                for _ in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops._lib.call("fs2_ldsdma_calibrate", src.data_ptr(), src.numel(), 2000, sink.data_ptr(), ctypes.byref(by), ops._stream())
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                t = sorted(ts[1:])[1]
+                roofline["l2_to_lds"] = {"tb_per_s": round(by.value / (t * 1e-3) / 1e12, 2),
+                                         "how": "global_load_lds_dwordx4 of a 1 MiB L2-resident window per XCD, every CU, 8 waves x 4 KiB in flight, median of 3"}
+                del src, dst
+            except Exception as e:
+                print(f"[bench] memory calibration failed ({type(e).__name__}: {e})", file=sys.stderr)
             # the weight-gradient kernels of the same replay (side stream off: each duration is the kernel's own).  They run on
             # the side stream in the timed step and are the largest block of device time after the contractions above.
             wrec = prof.get("conv_wgrad", [])

@@ -78,6 +78,10 @@ int fs2_conv_gemm_splitk(const void* X, long ldx, const void* Wpacked, const flo
  * iters x 8 MFMAs per wave); *flops receives the FLOPs of the launch.  bench.py times it to report what the matrix pipes SUSTAIN
  * under the chip's power management beside the nominal peak.  sink: one float of device memory (never written in practice). */
 int fs2_mfma_calibrate(int iters, float* sink, double* flops, fs2_stream_t stream);
+/* The memory-side calibrations reported beside it (roofline.hbm_copy / roofline.l2_to_lds): a 16-byte-per-lane copy of `bytes`
+ * (src -> dst), and an LDS-DMA stream of an L2-resident window on every CU (8 waves x 4 KiB in flight; *bytes = bytes moved). */
+int fs2_hbm_calibrate(const void* src, void* dst, size_t bytes, fs2_stream_t stream);
+int fs2_ldsdma_calibrate(const void* src, size_t src_bytes, int iters, float* sink, double* bytes, fs2_stream_t stream);
 /* Which kernel fs2_conv_gemm dispatches a launch description to: a pure function (no state) - a measurement aid that
  * lets bench.py attribute HIP-event durations to the kernel names rocprofv3 reports.  has_lens / has_map: whether
  * lens / tile_map would be non-NULL; ldr = 0 without a residual operand. */

@@ -33,6 +33,9 @@ def test_bench_line_contract(dev):
     assert 0 < r["frac_valid_rows"] <= r["frac"]                           # FLOPs of valid rows only (fully padded tiles are skipped)
     assert abs(r["gflop_per_launch"] * r["launches_per_step"] / r["kernel_ms_per_step"] - r["achieved"]) < 0.02 * r["achieved"]
     assert r["traffic"] is not None and r["traffic"]["bytes_per_launch"] > 0          # profiles/*_pmc_traffic.json travels with the repo
+    # what this box sustains, next to the nominal peaks: matrix pipes, HBM copy, L2 -> LDS-DMA stream
+    assert 0.5 < r["mfma_sustained"]["frac_of_nominal_peak"] <= 1.0
+    assert 2.0 < r["hbm_copy"]["tb_per_s"] < 8.0 and 2.0 < r["l2_to_lds"]["tb_per_s"] < 60.0
     # tamper evidence + measurement quality: the shipped library, no development variables, the timed
     # window repeated and the median reported, the reference's own arithmetic (fp32) as a secondary figure of the same line
     cfg = d["config"]
