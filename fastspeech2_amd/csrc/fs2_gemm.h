@@ -20,6 +20,11 @@ struct ConvGemmArgs {
     int act; float slope;          // output activation
     int in_act; float in_slope;    // activation applied to X on load (leaky-relu prologue of HiFi-GAN)
     int accumulate; float out_scale;
+    // HiFi-GAN's pre-activation chains store leaky-ReLU'd activations (round 5): a convolution then reads its operand without a
+    // prologue (the prologue cost 27-35 % of every launch that had one: 13 VALU per MFMA in the consumer's issue stream,
+    // profiles/r05l_bench_voc.log), and the two places that need the RAW value undo it:
+    float res_unlrelu;             // > 0: the residual operand R holds lrelu(r, slope) - use r > 0 ? r : r * res_unlrelu (= 1 / slope)
+    float post_slope;              // > 0: the value stored is lrelu(v, post_slope), applied last (after residual, scale, accumulate)
     int vec_ok;                    // Y / R rows are 16-byte addressable (ld % elems-per-16B == 0, aligned bases)
     int dbg;                       // dev ablations (FS2_GEMM_DBG): 1 = loaders issue no DMA, 2 = consumers issue no MFMA
 };

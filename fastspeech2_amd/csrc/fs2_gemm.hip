@@ -67,7 +67,10 @@ __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const flo
                 if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&rr); for (int e = 0; e < 4; ++e) rv[e] = f[e]; }
                 else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr); for (int e = 0; e < 4; ++e) { rv[2 * e] = __uint_as_float(u[e] << 16); rv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); } }
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) v[e] = gate ? (rv[e] > 0.f ? v[e] : 0.f) : v[e] + rv[e];
+                for (int e = 0; e < EPT; ++e) {
+                    if (a.res_unlrelu > 0.f) rv[e] = rv[e] > 0.f ? rv[e] : rv[e] * a.res_unlrelu;
+                    v[e] = gate ? (rv[e] > 0.f ? v[e] : 0.f) : v[e] + rv[e];
+                }
             }
 #pragma unroll
             for (int e = 0; e < EPT; ++e) { v[e] *= a.out_scale; if (padrow) v[e] = 0.f; }
@@ -76,6 +79,10 @@ __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const flo
                 if constexpr (sizeof(T) == 4) { const float* f = reinterpret_cast<const float*>(&yy); for (int e = 0; e < 4; ++e) v[e] += f[e]; }
                 else { const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy); for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); } }
             }
+            if (a.post_slope > 0.f) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.post_slope;
+            }
             uint4 o;
             if constexpr (sizeof(T) == 4) { float* f = reinterpret_cast<float*>(&o); for (int e = 0; e < 4; ++e) f[e] = v[e]; }
             else { uint32_t* u = reinterpret_cast<uint32_t*>(&o); for (int e = 0; e < 4; ++e) u[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]); }
@@ -83,10 +90,15 @@ __device__ __forceinline__ void gemm_store_tile(const ConvGemmArgs& a, const flo
         } else {
             for (int e = 0; e < EPT && n + e < a.N; ++e) {
                 float x = v[e];
-                if (rp) { float rv = Elem<T>::ld(rp + e); x = gate ? (rv > 0.f ? x : 0.f) : x + rv; }
+                if (rp) {
+                    float rv = Elem<T>::ld(rp + e);
+                    if (a.res_unlrelu > 0.f) rv = rv > 0.f ? rv : rv * a.res_unlrelu;
+                    x = gate ? (rv > 0.f ? x : 0.f) : x + rv;
+                }
                 x *= a.out_scale;
                 if (padrow) x = 0.f;
                 if (a.accumulate) x += Elem<T>::ld(yp + e);
+                if (a.post_slope > 0.f) x = x > 0.f ? x : x * a.post_slope;
                 Elem<T>::st(yp + e, x);
             }
         }
@@ -989,7 +1001,8 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, b
     // wide-tile one-tap kernel (fs2_gemm_w.hip): N a multiple of 256 - the Linear layers of the FFT blocks and their data gradients
     static const int w_on = fs2_dev_env("FS2_GEMM_W", 1);
     // streaming kernel with the weights in registers (fs2_gemm_s.hip): the K = 256 Linear layers and data gradients
-    if (!skinny && fs2_conv_gemm_s_ok(a, dtype)) { p.variant = FS2_GEMM_STREAM_K256; return p; }
+    const bool lrelu_io = a.res_unlrelu > 0.f || a.post_slope > 0.f;     // (the streaming kernel's own epilogue does not carry them)
+    if (!skinny && !lrelu_io && fs2_conv_gemm_s_ok(a, dtype)) { p.variant = FS2_GEMM_STREAM_K256; return p; }
     if (w_on && !skinny && fs2_conv_gemm_w_ok(a, has_map, dtype)) { p.variant = FS2_GEMM_WIDE_1TAP; return p; }
     p.variant = skinny ? FS2_GEMM_SKINNY : (persist ? (taps == 1 ? FS2_GEMM_PERSIST_1TAP : FS2_GEMM_PERSIST) : (big ? FS2_GEMM_RING : (dma ? FS2_GEMM_DMA : FS2_GEMM_PLAIN)));
     return p;
@@ -1003,6 +1016,7 @@ static void conv_gemm_fill(ConvGemmArgs& a, const void* X, long ldx, const void*
     a.lens = lens; a.M = M; a.N = N; a.Cin = Cin; a.S = S; a.taps = taps; a.dil = dil; a.pad = pad; a.act = act;
     a.slope = slope; a.in_act = in_act; a.in_slope = in_slope; a.accumulate = accumulate; a.out_scale = out_scale;
     a.dbg = 0;
+    a.res_unlrelu = 0.f; a.post_slope = 0.f;
     a.vec_ok = (ldy % epc == 0) && (((uintptr_t)Y & 15) == 0) && (!R || ((ldr % epc == 0) && (((uintptr_t)R & 15) == 0)));
 }
 
@@ -1019,7 +1033,7 @@ extern "C" int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens,
 static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
                           long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin, int S, int taps,
                           int dil, int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale,
-                          int dtype, hipStream_t stream) {
+                          int dtype, hipStream_t stream, float res_unlrelu = 0.f, float post_slope = 0.f) {
     FS2_CHECK_ARG(X && W && Y, "conv_gemm: null pointer");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0 && S > 0 && taps > 0 && dil > 0, "conv_gemm: bad shape M=%d N=%d Cin=%d S=%d taps=%d", M, N, Cin, S, taps);
     FS2_CHECK_ARG(M % S == 0, "conv_gemm: M=%d not a multiple of S=%d", M, S);
@@ -1032,6 +1046,9 @@ static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* b
     conv_gemm_fill(a, X, ldx, W, bias, R, ldr, Y, ldy, lens, M, N, Cin, S, taps, dil, pad, act, slope, in_act, in_slope, accumulate, out_scale, dtype);
     static const int gemm_dbg = fs2_dev_env("FS2_GEMM_DBG", 0);
     a.dbg = gemm_dbg;
+    FS2_CHECK_ARG(res_unlrelu >= 0.f && post_slope >= 0.f && post_slope < 1.f && (res_unlrelu == 0.f || (R && act != FS2_ACT_GATE)),
+                  "conv_gemm: res_unlrelu needs an additive residual operand, post_slope in [0, 1)");
+    a.res_unlrelu = res_unlrelu; a.post_slope = post_slope;
     const long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
     const GemmPick pk = conv_gemm_pick(a, dtype, tile_map != nullptr, tail_ws != nullptr);
@@ -1098,6 +1115,17 @@ extern "C" int fs2_conv_gemm_tail(const void* X, long ldx, const void* W, const 
     FS2_CHECK_ARG(!tail_ws || ((uintptr_t)tail_ws & 15) == 0, "conv_gemm_tail: tail_ws must be 16-byte aligned");
     return conv_gemm_impl(X, ldx, W, bias, R, ldr, Y, ldy, lens, tile_map, tail_ws, M, N, Cin, S, taps, dil, pad, act, slope, in_act,
                           in_slope, accumulate, out_scale, dtype, stream);
+}
+
+// fs2_conv_gemm_tail for chains that STORE leaky-ReLU'd activations (hifigan/models.py:96-103 as fastspeech2_amd/hifigan.py runs it):
+// res_unlrelu = 1 / slope when R holds lrelu(r) (the raw r is added), post_slope = slope when lrelu(value) is to be stored.
+extern "C" int fs2_conv_gemm_lrelu_io(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
+                                      long ldy, float* tail_ws, int M, int N, int Cin, int S, int taps, int dil, int pad, int act,
+                                      float slope, int accumulate, float out_scale, float res_unlrelu, float post_slope, int dtype,
+                                      hipStream_t stream) {
+    FS2_CHECK_ARG(!tail_ws || ((uintptr_t)tail_ws & 15) == 0, "conv_gemm_lrelu_io: tail_ws must be 16-byte aligned");
+    return conv_gemm_impl(X, ldx, W, bias, R, ldr, Y, ldy, nullptr, nullptr, tail_ws, M, N, Cin, S, taps, dil, pad, act, slope,
+                          FS2_ACT_NONE, 0.f, accumulate, out_scale, dtype, stream, res_unlrelu, post_slope);
 }
 
 // K-split form of fs2_conv_gemm for contractions with few output tiles and a long reduction (the encoder's k=9 data gradient:

@@ -63,7 +63,8 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
                     const uint32_t* u = reinterpret_cast<const uint32_t*>(&rr);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+                        float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+                        if (a.res_unlrelu > 0.f) { r0 = r0 > 0.f ? r0 : r0 * a.res_unlrelu; r1 = r1 > 0.f ? r1 : r1 * a.res_unlrelu; }
                         v[2 * e] = gate ? (r0 > 0.f ? v[2 * e] : 0.f) : v[2 * e] + r0;
                         v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
                     }
@@ -75,6 +76,10 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
                     const uint32_t* u = reinterpret_cast<const uint32_t*>(&yy);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(u[e] << 16); v[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u); }
+                }
+                if (a.post_slope > 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.post_slope;
                 }
                 uint4 o;
                 uint32_t* ou = reinterpret_cast<uint32_t*>(&o);

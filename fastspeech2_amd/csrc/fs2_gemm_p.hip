@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, co
         const uint32_t* u = reinterpret_cast<const uint32_t*>(&rv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+            float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+            if (a.res_unlrelu > 0.f) { r0 = r0 > 0.f ? r0 : r0 * a.res_unlrelu; r1 = r1 > 0.f ? r1 : r1 * a.res_unlrelu; }
             v[2 * e] = gate ? (r0 > 0.f ? v[2 * e] : 0.f) : v[2 * e] + r0;
             v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
         }
@@ -287,7 +288,11 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, co
     uint4 o;
     uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ou[e] = padrow ? 0u : pack_bf16x2(v[2 * e] * a.out_scale, v[2 * e + 1] * a.out_scale);
+    for (int e = 0; e < 4; ++e) {
+        float x0 = v[2 * e] * a.out_scale, x1 = v[2 * e + 1] * a.out_scale;
+        if (a.post_slope > 0.f) { x0 = x0 > 0.f ? x0 : x0 * a.post_slope; x1 = x1 > 0.f ? x1 : x1 * a.post_slope; }
+        ou[e] = padrow ? 0u : pack_bf16x2(x0, x1);
+    }
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = o;
 }
 
@@ -358,7 +363,8 @@ __global__ void __launch_bounds__(256) p_tail_finalize_kernel(ConvGemmArgs a, PS
         const uint32_t* u = reinterpret_cast<const uint32_t*>(&rv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+            float r0 = __uint_as_float(u[e] << 16), r1 = __uint_as_float(u[e] & 0xffff0000u);
+            if (a.res_unlrelu > 0.f) { r0 = r0 > 0.f ? r0 : r0 * a.res_unlrelu; r1 = r1 > 0.f ? r1 : r1 * a.res_unlrelu; }
             v[2 * e] = gate ? (r0 > 0.f ? v[2 * e] : 0.f) : v[2 * e] + r0;
             v[2 * e + 1] = gate ? (r1 > 0.f ? v[2 * e + 1] : 0.f) : v[2 * e + 1] + r1;
         }
@@ -368,7 +374,11 @@ __global__ void __launch_bounds__(256) p_tail_finalize_kernel(ConvGemmArgs a, PS
     uint4 o;
     uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ou[e] = padrow ? 0u : pack_bf16x2(v[2 * e] * a.out_scale, v[2 * e + 1] * a.out_scale);
+    for (int e = 0; e < 4; ++e) {
+        float x0 = v[2 * e] * a.out_scale, x1 = v[2 * e + 1] * a.out_scale;
+        if (a.post_slope > 0.f) { x0 = x0 > 0.f ? x0 : x0 * a.post_slope; x1 = x1 > 0.f ? x1 : x1 * a.post_slope; }
+        ou[e] = padrow ? 0u : pack_bf16x2(x0, x1);
+    }
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = o;
   }
 }

@@ -38,7 +38,7 @@ struct ResBlockArgs {
     const float* B1[3]; const float* B2[3]; // per block: [3][C] f32
     int k[3], nblk;
     void* XS; long ldxs;                // [M][C] bf16
-    int accumulate; float out_scale, slope;
+    int accumulate; float out_scale, slope, post_slope;
     int S, nbatch, d[3], R, tiles_per_seq;
 };
 
@@ -316,6 +316,10 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
             f32x16 v;
 #pragma unroll
             for (int i = 0; i < 8; ++i) { v[2 * i] = __uint_as_float(xs_pk[mb][nb][i] << 16); v[2 * i + 1] = __uint_as_float(xs_pk[mb][nb][i] & 0xffff0000u); }
+            if (a.post_slope > 0.f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.post_slope;
+            }
             float cc[2][8];
             to_rows(v, cc);
             if (store) {
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
                     uint4 o;
                     uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(cc[ch][2 * e], cc[ch][2 * e + 1]);       // (exact: the values are bf16 already)
+                    for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(cc[ch][2 * e], cc[ch][2 * e + 1]);       // (exact without post_slope: the values are bf16 already)
                     *reinterpret_cast<uint4*>(row + nb * 32 + ch * 16 + fh * 8) = o;
                 }
             }
@@ -355,12 +359,12 @@ extern "C" int fs2_resblock_supported(int C, int k, int d0, int d1, int d2, int 
 }
 
 static int resblocks_impl(const void* x, long ldx, int nblk, const void* const* w1, const void* const* w2, const float* const* b1,
-                          const float* const* b2, const int* k, void* xs, long ldxs, int accumulate, float out_scale, float slope, int B,
-                          int S, int C, int d0, int d1, int d2, int dtype, hipStream_t stream) {
+                          const float* const* b2, const int* k, void* xs, long ldxs, int accumulate, float out_scale, float slope,
+                          float post_slope, int B, int S, int C, int d0, int d1, int d2, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && xs && nblk >= 1 && nblk <= 3, "resblock_fwd: null pointer / block count");
     FS2_CHECK_ARG(B > 0 && S > 0, "resblock_fwd: bad shape");
     FS2_CHECK_ARG(ldx % 8 == 0 && ldxs % 8 == 0 && (((uintptr_t)x | (uintptr_t)xs) & 15) == 0, "resblock_fwd: rows must be 16-byte addressable");
-    FS2_CHECK_ARG(slope > 0.f && slope < 1.f, "resblock_fwd: leaky-ReLU slope in (0, 1)");
+    FS2_CHECK_ARG(slope > 0.f && slope < 1.f && post_slope >= 0.f && post_slope < 1.f, "resblock_fwd: leaky-ReLU slope in (0, 1)");
     ResBlockArgs a = {};
     int H = 0;
     for (int j = 0; j < nblk; ++j) {
@@ -372,7 +376,7 @@ static int resblocks_impl(const void* x, long ldx, int nblk, const void* const* 
     }
     a.nblk = nblk;
     a.X = x; a.ldx = ldx; a.XS = xs; a.ldxs = ldxs;
-    a.accumulate = accumulate; a.out_scale = out_scale; a.slope = slope; a.S = S; a.nbatch = B;
+    a.accumulate = accumulate; a.out_scale = out_scale; a.slope = slope; a.post_slope = post_slope; a.S = S; a.nbatch = B;
     a.d[0] = d0; a.d[1] = d1; a.d[2] = d2;
     const int E = C == 32 ? 1024 : 512;
     a.R = E - 2 * H;
@@ -384,19 +388,20 @@ static int resblocks_impl(const void* x, long ldx, int nblk, const void* const* 
 }
 
 extern "C" int fs2_resblock_fwd(const void* x, long ldx, const void* w1, const void* w2, const float* b1, const float* b2, void* xs,
-                                long ldxs, int accumulate, float out_scale, float slope, int B, int S, int C, int k, int d0, int d1,
-                                int d2, int dtype, hipStream_t stream) {
-    return resblocks_impl(x, ldx, 1, &w1, &w2, &b1, &b2, &k, xs, ldxs, accumulate, out_scale, slope, B, S, C, d0, d1, d2, dtype, stream);
+                                long ldxs, int accumulate, float out_scale, float slope, float post_slope, int B, int S, int C, int k,
+                                int d0, int d1, int d2, int dtype, hipStream_t stream) {
+    return resblocks_impl(x, ldx, 1, &w1, &w2, &b1, &b2, &k, xs, ldxs, accumulate, out_scale, slope, post_slope, B, S, C, d0, d1, d2, dtype,
+                          stream);
 }
 
 extern "C" int fs2_resstage_fwd(const void* x, long ldx, const void* w1a, const void* w2a, const float* b1a, const float* b2a, int ka,
                                 const void* w1b, const void* w2b, const float* b1b, const float* b2b, int kb, const void* w1c,
                                 const void* w2c, const float* b1c, const float* b2c, int kc, void* xs, long ldxs, float out_scale,
-                                float slope, int B, int S, int C, int d0, int d1, int d2, int dtype, hipStream_t stream) {
+                                float slope, float post_slope, int B, int S, int C, int d0, int d1, int d2, int dtype, hipStream_t stream) {
     const void* w1[3] = {w1a, w1b, w1c};
     const void* w2[3] = {w2a, w2b, w2c};
     const float* b1[3] = {b1a, b1b, b1c};
     const float* b2[3] = {b2a, b2b, b2c};
     const int k[3] = {ka, kb, kc};
-    return resblocks_impl(x, ldx, 3, w1, w2, b1, b2, k, xs, ldxs, 0, out_scale, slope, B, S, C, d0, d1, d2, dtype, stream);
+    return resblocks_impl(x, ldx, 3, w1, w2, b1, b2, k, xs, ldxs, 0, out_scale, slope, post_slope, B, S, C, d0, d1, d2, dtype, stream);
 }

@@ -181,74 +181,91 @@ class Generator(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _run(self, x_rows, B, T, want_wav, want_pcm, max_wav_value):
-        """x_rows: [B*T][80] in the compute dtype.  Returns (wav f32 (B, T*hop) | None, pcm int16 (B, T*hop) | None)."""
+        """x_rows: [B*T][80] in the compute dtype.  Returns (wav f32 (B, T*hop) | None, pcm int16 (B, T*hop) | None).
+
+        Storage convention (round 5): every convolution of the generator reads leaky_relu(x, 0.1) (models.py:98-100, 152), so the chains of
+        single launches STORE leaky_relu(value) and read it without a prologue (the in-kernel prologue cost 27-35 % of every launch that
+        had one); the raw value is needed in two places only and undone there on the fly (r > 0 ? r : r / slope): the residual add of a
+        block's conv2, and what the tests probe.  A stage whose residual blocks run fused (C <= 64) takes and keeps raw rows - the
+        running sum never leaves registers there - and hands leaky_relu(xs) to the next up-sampling convolution.  `lre` below says
+        which form the current `x` is in.  The last stage's output stays raw: conv_post applies ITS leaky_relu (slope 0.01, models.py:161)."""
         h = self.h
         W = self._weights(x_rows.device)
         S = T
+        SL, INV = LRELU_SLOPE, 1.0 / LRELU_SLOPE
         wp, bp = W["pre"]
-        x = ops.conv_gemm(x_rows, wp, bp, S, taps=7, pad=3)
+        x = ops.conv_gemm(x_rows, wp, bp, S, taps=7, pad=3, post_slope=SL)                # stored leaky-ReLU'd: up0 reads it as it is
+        lre = True
+
+        def raw(t):
+            """fp32 copy of a stored activation in its RAW form (tests' stage probe only)"""
+            t = t.float()
+            return torch.where(t > 0, t, t * INV)
+
         if self.stage_probe is not None:
-            self.stage_probe.append((x, S))
+            self.stage_probe.append((raw(x), S))
         nk = self.num_kernels
+        nup = len(h["upsample_rates"])
         for i, u in enumerate(h["upsample_rates"]):
             wu, bu, taps, pad = W[f"up{i}"]
             cout = wu.shape[0] // u
-            y = ops.conv_gemm(x, wu, bu, S, taps=taps, pad=pad, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
+            fz = [W.get(f"rb{i * nk + j}.fused") for j in range(nk)] if self.fuse_resblocks else [None] * nk
+            dils = {self.resblocks[i * nk + j].dilations for j in range(nk)}
+            fused = all(f is not None for f in fz) and len(dils) == 1 and nk == 3
+            out_sl = SL if i + 1 < nup else 0.0             # what the NEXT consumer wants: lrelu'd for an up-sampling conv, raw for conv_post
+            assert lre
+            # the polyphase transposed convolution: its input is stored lrelu'd (no prologue); its output feeds a fused stage raw,
+            # a chain of single launches lrelu'd
+            y = ops.conv_gemm(x, wu, bu, S, taps=taps, pad=pad, post_slope=0.0 if fused else SL)
             S = S * u
             x = y.view(B * S, cout)
-            xs = None
-            fz = [W.get(f"rb{i * nk + j}.fused") for j in range(nk)] if self.fuse_resblocks else [None]
-            dils = {self.resblocks[i * nk + j].dilations for j in range(nk)}
-            if nk == 3 and all(f is not None for f in fz) and len(dils) == 1 and self.fuse_resblocks != "block":
+            ks = [self.resblocks[i * nk + j].kernel_size for j in range(nk)]
+            if fused and self.fuse_resblocks != "block":
                 # the whole stage's residual blocks in ONE launch: x read once, xs written once
                 xs = torch.empty_like(x)
-                ks = [self.resblocks[i * nk + j].kernel_size for j in range(nk)]
                 args = []
                 for j in range(nk):
                     args += [fz[j][0].data_ptr(), fz[j][1].data_ptr(), fz[j][2].data_ptr(), fz[j][3].data_ptr(), ks[j]]
                 if ops.PROFILE is not None:          # bench.py's roofline replay: HIP events around the launch, algorithmic FLOPs
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                _lib.call("fs2_resstage_fwd", x.data_ptr(), x.stride(0), *args, xs.data_ptr(), xs.stride(0), 1.0 / nk, LRELU_SLOPE,
+                _lib.call("fs2_resstage_fwd", x.data_ptr(), x.stride(0), *args, xs.data_ptr(), xs.stride(0), 1.0 / nk, SL, out_sl,
                           B, S, x.shape[1], *next(iter(dils)), ops.dt(x), ops._stream())
                 if ops.PROFILE is not None:
                     e1.record()
                     C_ = x.shape[1]
                     ops.PROFILE.setdefault("conv_gemm", []).append((2.0 * B * S * C_ * C_ * sum(ks) * 6, e0, e1, 10, False, S))
-                x = xs
-                if self.stage_probe is not None:
-                    self.stage_probe.append((x, S))
-                continue
-            for j in range(nk):
-                rb = self.resblocks[i * nk + j]
-                rk = rb.kernel_size
-                fused = W.get(f"rb{i * nk + j}.fused") if self.fuse_resblocks else None
-                if fused is not None:               # the whole block in one launch (x read once, xs read + written once)
-                    if xs is None:
-                        xs = torch.empty_like(x)
-                        acc = False
-                    else:
-                        acc = True
-                    _lib.call("fs2_resblock_fwd", x.data_ptr(), x.stride(0), fused[0].data_ptr(), fused[1].data_ptr(),
-                              fused[2].data_ptr(), fused[3].data_ptr(), xs.data_ptr(), xs.stride(0), int(acc), 1.0 / nk, LRELU_SLOPE,
-                              B, S, x.shape[1], rk, *rb.dilations, ops.dt(x), ops._stream())
-                    continue
-                cur = x
-                nd = len(rb.dilations)
-                for m, d in enumerate(rb.dilations):
-                    w1, b1 = W[f"rb{i * nk + j}.1.{m}"]
-                    w2, b2 = W[f"rb{i * nk + j}.2.{m}"]
-                    # t = lrelu(conv1(lrelu(cur))): the second leaky-ReLU is applied to conv1's accumulators
-                    t = ops.conv_gemm(cur, w1, b1, S, taps=rk, dil=d, pad=get_padding(rk, d), in_act=ACT_LRELU,
-                                      in_slope=LRELU_SLOPE, act=ACT_LRELU, slope=LRELU_SLOPE)
-                    if m < nd - 1:
-                        cur = ops.conv_gemm(t, w2, b2, S, taps=rk, pad=get_padding(rk, 1), res=cur)
-                    else:   # last conv of the branch: xs (+)= (conv + cur) / num_kernels   (models.py:155-160)
-                        xs = ops.conv_gemm(t, w2, b2, S, taps=rk, pad=get_padding(rk, 1), res=cur, out=xs,
-                                           accumulate=xs is not None, out_scale=1.0 / nk)
+            elif fused:
+                # one launch per block (A/B form): the last one also applies the output leaky-ReLU
+                xs = None
+                for j in range(nk):
+                    rb = self.resblocks[i * nk + j]
+                    xs = ops.resblock_fwd(x, fz[j][0], fz[j][1], fz[j][2], fz[j][3], B, S, ks[j], rb.dilations, xs=xs, out_scale=1.0 / nk,
+                                          slope=SL, post_slope=out_sl if j == nk - 1 else 0.0)
+            else:
+                xs = None
+                for j in range(nk):
+                    rb = self.resblocks[i * nk + j]
+                    rk = rb.kernel_size
+                    cur = x                                 # lrelu'd rows
+                    nd = len(rb.dilations)
+                    for m, d in enumerate(rb.dilations):
+                        w1, b1 = W[f"rb{i * nk + j}.1.{m}"]
+                        w2, b2 = W[f"rb{i * nk + j}.2.{m}"]
+                        # t = lrelu(conv1(lrelu(cur))): the operand is stored lrelu'd, the second leaky-ReLU runs on conv1's accumulators
+                        t = ops.conv_gemm(cur, w1, b1, S, taps=rk, dil=d, pad=get_padding(rk, d), act=ACT_LRELU, slope=SL)
+                        if m < nd - 1:                      # cur <- lrelu(conv2(t) + raw cur)
+                            cur = ops.conv_gemm(t, w2, b2, S, taps=rk, pad=get_padding(rk, 1), res=cur, res_unlrelu=INV, post_slope=SL)
+                        else:   # last conv of the branch: xs (+)= (conv + raw cur) / num_kernels (models.py:155-160); the stage's last
+                                # launch stores what the next consumer reads
+                            xs = ops.conv_gemm(t, w2, b2, S, taps=rk, pad=get_padding(rk, 1), res=cur, res_unlrelu=INV, out=xs,
+                                               accumulate=xs is not None, out_scale=1.0 / nk,
+                                               post_slope=out_sl if j == nk - 1 else 0.0)
             x = xs
+            lre = out_sl > 0
             if self.stage_probe is not None:
-                self.stage_probe.append((x, S))
+                self.stage_probe.append((raw(x) if lre else x, S))
+        assert not lre
         wpost, bpost = W["post"]
         M = B * S
         wav = torch.empty(B, S, device=x.device, dtype=torch.float32) if want_wav else None

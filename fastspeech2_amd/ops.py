@@ -91,7 +91,7 @@ def pack_weight(w, dtype, want_fwd=True, want_dgrad=True, wf=None, wd=None):
 # ------------------------------------------------------------------ contraction
 def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0, lens=None, res=None, out=None,
               in_act=ACT_NONE, in_slope=0.0, accumulate=False, out_scale=1.0, ldx=None, M=None, Cin=None, N=None,
-              ldy=None, tmap=None, ksplit=1, ws=None, tail_ws=None, ragged=None):
+              ldy=None, tmap=None, ksplit=1, ws=None, tail_ws=None, ragged=None, res_unlrelu=0.0, post_slope=0.0):
     """x: [M, Cin] rows (or any buffer with row stride ldx); wpacked: [N, taps, Cin]; returns [M, N].
     tmap: tile_map(lens, B, S) of the same lens (optional; lets the persistent kernel skip fully padded M-tiles).
     ragged: bookkeeping only (bench.py's valid-row FLOP count) - the rows hold ragged sequences although the launch itself does
@@ -113,7 +113,11 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if ksplit > 1:      # few output tiles, long reduction: K-split workgroups + f32 scratch slabs (ksplit x M x N) + finalize launch
+    if res_unlrelu or post_slope:          # stored-leaky-ReLU chains (HiFi-GAN): fs2_conv_gemm_lrelu_io
+        assert ksplit == 1 and lens is None and in_act == ACT_NONE
+        _lib.call("fs2_conv_gemm_lrelu_io", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(tail_ws), M, N, Cin, S, taps,
+                  dil, pad, act, slope, int(accumulate), out_scale, res_unlrelu, post_slope, dt(x), _stream())
+    elif ksplit > 1:      # few output tiles, long reduction: K-split workgroups + f32 scratch slabs (ksplit x M x N) + finalize launch
         assert ws is not None and ws.numel() >= ksplit * M * N and ws.dtype == torch.float32 and in_act == ACT_NONE and not accumulate
         _lib.call("fs2_conv_gemm_splitk", _p(x), ldx, _p(wpacked), _p(bias), _p(res), ldr, _p(out), ldy, _p(lens), _p(tmap), _p(ws),
                   ksplit, M, N, Cin, S, taps, dil, pad, act, slope, out_scale, dt(x), _stream())
@@ -132,7 +136,7 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
     return out
 
 
-def resblock_fwd(x, w1, w2, b1, b2, B, S, k, dilations, xs=None, out_scale=1.0, slope=0.1):
+def resblock_fwd(x, w1, w2, b1, b2, B, S, k, dilations, xs=None, out_scale=1.0, slope=0.1, post_slope=0.0):
     """a whole HiFi-GAN ResBlock1 (hifigan/models.py:96-103) on rows x [B*S][C] in one launch (fs2_resblock_fwd; C in {32, 64}, bf16):
     xs = (xs if given else 0) + out_scale * block(x).  w1 / w2: [3][C][k][C], b1 / b2: [3][C] f32."""
     acc = xs is not None
@@ -140,11 +144,11 @@ def resblock_fwd(x, w1, w2, b1, b2, B, S, k, dilations, xs=None, out_scale=1.0, 
         xs = torch.empty_like(x)
     d0, d1, d2 = dilations
     _lib.call("fs2_resblock_fwd", _p(x), x.stride(0), _p(w1), _p(w2), _p(b1), _p(b2), _p(xs), xs.stride(0), int(acc), out_scale, slope,
-              B, S, x.shape[1], k, d0, d1, d2, dt(x), _stream())
+              post_slope, B, S, x.shape[1], k, d0, d1, d2, dt(x), _stream())
     return xs
 
 
-def resstage_fwd(x, blocks, B, S, dilations, out_scale=1.0 / 3, slope=0.1):
+def resstage_fwd(x, blocks, B, S, dilations, out_scale=1.0 / 3, slope=0.1, post_slope=0.0):
     """the three residual blocks of one up-sampling stage in one launch (fs2_resstage_fwd): blocks = [(w1, w2, b1, b2, k)] x 3;
     returns xs = out_scale * sum of the blocks' outputs."""
     xs = torch.empty_like(x)
@@ -152,8 +156,8 @@ def resstage_fwd(x, blocks, B, S, dilations, out_scale=1.0 / 3, slope=0.1):
     for w1, w2, b1, b2, k in blocks:
         args += [_p(w1), _p(w2), _p(b1), _p(b2), k]
     d0, d1, d2 = dilations
-    _lib.call("fs2_resstage_fwd", _p(x), x.stride(0), *args, _p(xs), xs.stride(0), out_scale, slope, B, S, x.shape[1], d0, d1, d2, dt(x),
-              _stream())
+    _lib.call("fs2_resstage_fwd", _p(x), x.stride(0), *args, _p(xs), xs.stride(0), out_scale, slope, post_slope, B, S, x.shape[1], d0, d1, d2,
+              dt(x), _stream())
     return xs
 
 

@@ -74,6 +74,13 @@ int fs2_conv_gemm_splitk(const void* X, long ldx, const void* Wpacked, const flo
                          long ldy, const int32_t* lens, const int32_t* tile_map, float* ws, int ksplit, int M, int N, int Cin,
                          int S, int taps, int dil, int pad, int act, float slope, float out_scale, int dtype,
                          fs2_stream_t stream);
+/* fs2_conv_gemm_tail for HiFi-GAN's pre-activation chains when the activations are STORED leaky-ReLU'd (hifigan/models.py:96-103:
+ * every convolution's input is leaky_relu(x), the residual is the raw x): the producer stores lrelu(value) (post_slope = slope,
+ * applied last: after residual, out_scale and accumulate), the next convolution reads it with no prologue, and a residual operand
+ * stored that way is undone on the fly (res_unlrelu = 1 / slope: r > 0 ? r : r * res_unlrelu).  0 switches either off. */
+int fs2_conv_gemm_lrelu_io(const void* X, long ldx, const void* Wpacked, const float* bias, const void* R, long ldr, void* Y,
+                           long ldy, float* tail_ws, int M, int N, int Cin, int S, int taps, int dil, int pad, int act, float slope,
+                           int accumulate, float out_scale, float res_unlrelu, float post_slope, int dtype, fs2_stream_t stream);
 /* Measurement aid: a back-to-back v_mfma_f32_32x32x16_bf16 stream on every SIMD of the chip (one 256-thread workgroup per CU,
  * iters x 8 MFMAs per wave); *flops receives the FLOPs of the launch.  bench.py times it to report what the matrix pipes SUSTAIN
  * under the chip's power management beside the nominal peak.  sink: one float of device memory (never written in practice). */
@@ -250,18 +257,19 @@ int fs2_conv_post_pcm(const void* x, long ldx, const float* w, const float* bias
  *   y = x; for m in 0..2: t = lrelu(conv1_m(lrelu(y), dilation d_m)); y = conv2_m(t) + y;  xs = (accumulate ? xs : 0) + out_scale * y
  * x / xs: rows [B*S][C] (time-major); w1 / w2: [3][C][k][C] (convs1 / convs2 of the block, cout-major, tap, cin), b1 / b2: [3][C] f32.
  * The running sum stays in fp32 registers, the convolutions' operands in LDS: x is read once, xs read + written once.
+ * post_slope > 0: the xs written is leaky_relu(xs, post_slope) (the next up-sampling convolution then needs no prologue).
  * fs2_resblock_supported: 1 when a (C, k, dilations, dtype) combination has an instantiation (else run the convolutions one by one). */
 int fs2_resblock_supported(int C, int k, int d0, int d1, int d2, int dtype);
 int fs2_resblock_fwd(const void* x, long ldx, const void* w1, const void* w2, const float* b1, const float* b2, void* xs,
-                     long ldxs, int accumulate, float out_scale, float slope, int B, int S, int C, int k, int d0, int d1, int d2,
-                     int dtype, fs2_stream_t stream);
+                     long ldxs, int accumulate, float out_scale, float slope, float post_slope, int B, int S, int C, int k, int d0,
+                     int d1, int d2, int dtype, fs2_stream_t stream);
 /* models.py:155-160 for a whole up-sampling stage: the three residual blocks (kernel sizes ka / kb / kc, same dilations) of one x
  * in ONE launch - xs = out_scale * (block_a(x) + block_b(x) + block_c(x)), the running xs rounded to the storage dtype after
  * every block (as the per-block launches stored it): x is read once from HBM (twice more from L2), xs written once. */
 int fs2_resstage_fwd(const void* x, long ldx, const void* w1a, const void* w2a, const float* b1a, const float* b2a, int ka,
                      const void* w1b, const void* w2b, const float* b1b, const float* b2b, int kb, const void* w1c,
                      const void* w2c, const float* b1c, const float* b2c, int kc, void* xs, long ldxs, float out_scale,
-                     float slope, int B, int S, int C, int d0, int d1, int d2, int dtype, fs2_stream_t stream);
+                     float slope, float post_slope, int B, int S, int C, int d0, int d1, int d2, int dtype, fs2_stream_t stream);
 /* stft.py:60-66: xp[b][i] = y[b][reflect(i - P)], i < N + 2P; zero-filled up to row_len. */
 int fs2_reflect_pad(const float* y, float* xp, int B, int N, int P, long row_len, fs2_stream_t stream);
 /* The same for a ragged batch (preprocessor/preprocessor.py:194 over a corpus): row b holds lens[b] samples (row stride ldy,

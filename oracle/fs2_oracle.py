@@ -405,47 +405,74 @@ def bf16_store(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def hifigan_forward_stored(sd, h, mel, store=None, stages=None, stage_inputs=None, weight_store=None):
-    """hifigan_forward with the PRODUCT's storage points made explicit (fastspeech2_amd/hifigan.py `_run`): `store` is applied
-    wherever the product writes an activation to HBM in its compute dtype - the mel rows, every convolution's output (after
-    the fused leaky-ReLU / residual / `xs / 3` accumulate epilogue) and the leaky-ReLU'd operand of the pre-activation
-    convolutions (the LDS-DMA prologue re-rounds it) - and `weight_store` to the packed weights (conv_post's stay fp32).
+def hifigan_forward_stored(sd, h, mel, store=None, stages=None, stage_inputs=None, weight_store=None, fused_max_channels=64):
+    """hifigan_forward with the PRODUCT's storage points made explicit (fastspeech2_amd/hifigan.py `_run`, round-5 convention): `store`
+    is applied wherever the product writes an activation to HBM (or, inside a fused residual block, to LDS) in its compute dtype,
+    `weight_store` to the packed weights (conv_post's stay fp32).
+      * every convolution of the generator reads leaky_relu(x, 0.1), so the chains of single launches store leaky_relu(value) ONCE
+        (no separate stored x + re-rounded prologue operand as in rounds 1-4) and undo it where the raw value is needed: the
+        residual add of a block's conv2 (`unl`: a > 0 ? a : a / 0.1);
+      * stages whose channel count is <= fused_max_channels run their residual blocks fused (fs2_resblock.hip): the running sum y is
+        NOT rounded between the three pairs, only the convolutions' operands (leaky_relu(y), t) are, and the stage's running xs is
+        rounded after every block; the stage hands leaky_relu(xs) to the next up-sampling convolution, raw xs to conv_post.
     With store = weight_store = None this is hifigan_forward up to summation order (tests/test_oracle_golden.py); with
     bf16_store it is the bf16 EMULATION the bf16 bars are derived from (the product differs from it by accumulation order only).
-    stages: list that receives the output of conv_pre and of every up-sampling stage; stage_inputs: tensors to use as the INPUT
-    of stage i instead (i = 0: conv_pre <- mel ... len-1: conv_post) - per-stage comparisons that do not compound."""
+    stages: list that receives the RAW output of conv_pre and of every up-sampling stage; stage_inputs: RAW tensors to use as the
+    INPUT of stage i instead (i = 0: conv_pre <- mel ... len-1: conv_post) - per-stage comparisons that do not compound."""
     st = store if store is not None else (lambda t: t)
     wst = weight_store if weight_store is not None else (lambda t: t)
+    lre = lambda t: F.leaky_relu(t, 0.1)
+    unl = lambda a: torch.where(a > 0, a, a * 10.0)
 
     def inp(i, x):
         return stage_inputs[i] if (stage_inputs is not None and stage_inputs[i] is not None) else x
 
     x = F.conv1d(st(inp(0, mel)), wst(sd["conv_pre.weight"]), sd["conv_pre.bias"], padding=3)
-    x = st(x)
+    xl = st(lre(x))                                         # what is stored; unl(xl) is the raw value the product can still recover
     if stages is not None:
-        stages.append(x)
+        stages.append(unl(xl))
     nk = len(h["resblock_kernel_sizes"])
+    nup = len(h["upsample_rates"])
+    x = None
     for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
-        x = inp(1 + i, x)
-        x = F.conv_transpose1d(st(F.leaky_relu(x, 0.1)), wst(sd[f"ups.{i}.weight"]), sd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
-        x = st(x)
+        if stage_inputs is not None and stage_inputs[1 + i] is not None:
+            xl = st(lre(stage_inputs[1 + i]))               # (re-rounds to exactly the stored value when the input is the product's probe)
+        up = F.conv_transpose1d(xl, wst(sd[f"ups.{i}.weight"]), sd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+        fused = up.shape[1] <= fused_max_channels
+        last = i + 1 == nup
         xs = None
+        x0 = st(up) if fused else st(lre(up))               # fused stages keep raw rows, the chains lrelu'd ones
         for j, (rk, rd) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
             pre = f"resblocks.{i * nk + j}."
-            y = x
-            for m, d in enumerate(rd):
-                t = F.conv1d(st(F.leaky_relu(y, 0.1)), wst(sd[f"{pre}convs1.{m}.weight"]), sd[f"{pre}convs1.{m}.bias"], dilation=d,
-                             padding=(rk * d - d) // 2)
-                t = st(F.leaky_relu(t, 0.1))
-                t = F.conv1d(t, wst(sd[f"{pre}convs2.{m}.weight"]), sd[f"{pre}convs2.{m}.bias"], padding=(rk - 1) // 2) + y
-                if m < len(rd) - 1:
-                    y = st(t)
-                else:                                   # last conv of the branch: xs (+)= (conv + y) / nk, stored each time
-                    xs = st(t / nk) if xs is None else st(xs + t / nk)
-        x = xs
+            if fused:
+                y = x0
+                for m, d in enumerate(rd):
+                    t = F.conv1d(st(lre(y)), wst(sd[f"{pre}convs1.{m}.weight"]), sd[f"{pre}convs1.{m}.bias"], dilation=d, padding=(rk * d - d) // 2)
+                    y = F.conv1d(st(lre(t)), wst(sd[f"{pre}convs2.{m}.weight"]), sd[f"{pre}convs2.{m}.bias"], padding=(rk - 1) // 2) + y
+                xs = st(y / nk) if xs is None else st(xs + y / nk)
+            else:
+                cur = x0                                    # lrelu'd
+                for m, d in enumerate(rd):
+                    t = F.conv1d(cur, wst(sd[f"{pre}convs1.{m}.weight"]), sd[f"{pre}convs1.{m}.bias"], dilation=d, padding=(rk * d - d) // 2)
+                    t = st(lre(t))
+                    ynew = F.conv1d(t, wst(sd[f"{pre}convs2.{m}.weight"]), sd[f"{pre}convs2.{m}.bias"], padding=(rk - 1) // 2) + unl(cur)
+                    if m < len(rd) - 1:
+                        cur = st(lre(ynew))
+                    else:
+                        v = ynew / nk if xs is None else xs + ynew / nk
+                        # the stage's last launch stores what the next consumer reads: lrelu'd for an up-sampling conv, raw for conv_post
+                        xs = st(lre(v)) if (j == nk - 1 and not last) else st(v)
+        if fused and not last:
+            xl = st(lre(xs))
+            x = unl(xl)
+        elif not last:
+            xl = xs
+            x = unl(xl)
+        else:
+            x = xs
         if stages is not None:
             stages.append(x)
-    x = inp(1 + len(h["upsample_rates"]), x)
+    x = inp(1 + nup, x)
     x = F.leaky_relu(x)
     x = F.conv1d(x, sd["conv_post.weight"], sd["conv_post.bias"], padding=3)
     return torch.tanh(x)

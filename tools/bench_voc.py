@@ -58,6 +58,8 @@ for i, (u, k) in enumerate(zip((8, 8, 2, 2), (16, 16, 4, 4))):
         for rk in (3, 7, 11):
             for d in (1, 3, 5):
                 conv(f"stage{i} C={C} k={rk} conv1 d={d}", S, C, C, rk, dil=d, in_act=True, count=1)
+                if os.environ.get("VOC_NO_PROLOGUE"):      # the same launch without the leaky-ReLU prologue: what the prologue costs
+                    conv(f"   (no prologue) k={rk} d={d}", S, C, C, rk, dil=d, in_act=False, count=0)
             conv(f"stage{i} C={C} k={rk} conv2 (+res)", S, C, C, rk, res=True, count=3)
 tot = sum(c * ms for _, c, ms, _, _ in rows)
 print(f"sum over the launches above (x count): {tot:.3f} ms; {sum(c * fl for _, c, _, fl, _ in rows) / tot / 1e9:.0f} TF")
