@@ -33,6 +33,10 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
         if (a.lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }
         bf16_t* yrow = Y + (size_t)m * a.ldy;
         const bf16_t* rrow = R ? R + (size_t)m * a.ldr : nullptr;
+        // (The residual / old-Y chunks are loaded where they are used: load, wait, add, store, chunk by chunk - the ISA shows a
+        // vmcnt(0) behind every load once a store is pending.  Hoisting them ahead of the stores - all 16 of a tile, 8 per row block,
+        // 4 per pair of column blocks - spilled 50 / 9 / 0 registers of the 256 and the spill-free form measured SLOWER on one box:
+        // batch synthesis 7.30 -> 7.52 ms, train step 8.40 -> 8.48 ms (profiles/r05p_ab_*_epilogue_hoist.log).  Not kept.)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             float c[2][8];
