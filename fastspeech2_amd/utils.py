@@ -94,36 +94,17 @@ def get_vocoder(config, device, hifigan_dir="hifigan", compute_dtype="fp32", all
     return vocoder
 
 
-_PCM_HOST = {}
-
-
-def _pinned_like(t):
-    """a pinned host buffer for `t` (kept per shape / dtype and reused: pinning costs more than the copy)"""
-    key = (tuple(t.shape), t.dtype)
-    buf = _PCM_HOST.get(key)
-    if buf is None:
-        if len(_PCM_HOST) > 64:
-            _PCM_HOST.clear()
-        buf = _PCM_HOST[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    return buf
-
-
 def vocoder_infer(mels, vocoder, model_config, preprocess_config, lengths=None):
     """utils/model.py:74-92: mels (B, 80, T) -> list of int16 numpy arrays (cut to `lengths` samples).
-    `lengths` may be a device tensor: it is read AFTER the vocoder's launches are queued (the reference's `.tolist()` in front of
-    the vocoder is a device round trip with an idle GPU behind it), and the PCM comes back in ONE asynchronous copy into pinned
-    memory (a pageable `.cpu()` of a batch's 2-3 MB is staged by the runtime in ~30 KB pieces: ~90 copy kernels per batch)."""
+    (The PCM comes back with a plain `.cpu()`: a cached pinned buffer + asynchronous copy + reading `lengths` behind the vocoder's
+    launches was measured twice - r03s: 8.77 vs 8.66 ms per batch, r05q: 7.63 vs 7.59 - and is no faster.)"""
     name = model_config["vocoder"]["model"]
     assert name == "HiFi-GAN"
+    if torch.is_tensor(lengths):
+        lengths = lengths.tolist()
     with torch.no_grad():
         pcm = vocoder.infer_pcm(mels, preprocess_config["preprocessing"]["audio"]["max_wav_value"])
-        host = _pinned_like(pcm)
-        host.copy_(pcm, non_blocking=True)
-        if torch.is_tensor(lengths):
-            lengths = lengths.tolist()                       # (synchronises: the copy above has landed behind it)
-        else:
-            torch.cuda.current_stream(pcm.device).synchronize()
-    wavs = [w.copy() for w in host.numpy()]                  # (the pinned buffer is reused by the next batch)
+    wavs = [w for w in pcm.cpu().numpy()]
     for i in range(len(mels)):
         if lengths is not None:
             wavs[i] = wavs[i][: lengths[i]]
