@@ -31,6 +31,32 @@ def run_train(model, pcfg, mcfg, b, dev):
     return out, losses
 
 
+def test_length_hints_never_change_results(dev):
+    """FastSpeech2.set_length_hint only steers whether the contractions skip padded tiles: a hint for one side only
+    falls back to the tensor's own host copy on the other, a hint left over from ANOTHER batch (wrong size) is dropped - and in
+    every case the outputs are those of the hint-free forward."""
+    pcfg, mcfg = configs.make(dropout=False, dec_layers=2, enc_layers=2)
+    model = make_model(pcfg, mcfg, "bf16")
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 4))
+    model.to(dev).train()
+    model.disable_dropout = True
+    b = synthetic_batch(9, 6, 40, min_len_frac=0.3)
+    d = to_dev(b, dev)
+    args = (d["speakers"], d["texts"], d["src_lens"], d["max_src_len"], d["mels"], d["mel_lens"], d["max_mel_len"], d["pitches"],
+            d["energies"], d["durations"])
+    with torch.no_grad():
+        ref = model(*args)
+        outs = []
+        for hint in ((None, b["mel_lens"].numpy()), (b["src_lens"].numpy(), None), (np.array([3, 4]), np.array([30, 40])),
+                     (b["src_lens"].numpy(), b["mel_lens"].numpy())):
+            model.set_length_hint(*hint)
+            outs.append(model(*args))
+            assert model._engine.length_hint is None                     # consumed (or dropped) by that forward
+    for o in outs:
+        assert torch.equal(o[9], ref[9])
+        assert (o[1].float() - ref[1].float()).abs().max().item() <= 2e-2 * ref[1].float().abs().max().item()
+
+
 @pytest.mark.parametrize("tag", list(TRAIN_CASES))
 def test_train_step_matches_reference_golden(dev, tag):
     c = TRAIN_CASES[tag]
