@@ -994,7 +994,14 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, b
     // persistent 256x128 kernel (fs2_gemm_p.hip): every shape the ring kernel takes plus the short-K one-tap contractions
     // (its run-ahead loaders hide the per-tile ring fill those could not amortise).  FS2_GEMM_P=0: dev A/B against the ring.
     static const int p_on = fs2_dev_env("FS2_GEMM_P", 1);
-    const bool persist = p_on && !skinny && fs2_conv_gemm_p_ok(a, has_map, dtype, 1) && (taps > 1 || Cin >= 256);
+    // HiFi-GAN's stored-leaky-ReLU chain launches WITH a residual / accumulate operand and a short reduction (conv2 of a block: 6 - 44
+    // K-steps): the ring kernel's LDS-staged epilogue reads the operand four chunks at a time, the persistent kernel's register
+    // epilogue one chunk at a time behind its own stores (a vmcnt(0) each) - same box, `tools/bench_voc.py`: 116.7 -> 97.2 us (C = 128,
+    // k = 3), 146.3 -> 132.7 (k = 7), 89.8 -> 85.3 (C = 256, k = 11); without such an operand the persistent kernel is the faster one
+    // at every shape (profiles/r05t_bench_voc_ring.log).  Scoped to the launches it was measured on.
+    const bool res_short = (a.res_unlrelu > 0.f || a.post_slope > 0.f) && (a.R || a.accumulate) && a.act != FS2_ACT_GATE &&
+                           (long)taps * ((Cin + 63) / 64) <= 48 && big;
+    const bool persist = p_on && !skinny && !res_short && fs2_conv_gemm_p_ok(a, has_map, dtype, 1) && (taps > 1 || Cin >= 256);
     // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
     static const int ksplit_on = fs2_dev_env("FS2_GEMM_KSPLIT", 1);
     p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= 32;
