@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph-line", action="store_true", help="skip the hipGraph replay of the same step reported beside the eager number")
     ap.add_argument("--no-synth", action="store_true", help="train mode: skip the batch-synthesis RTF object (config.synth)")
+    ap.add_argument("--no-synth-pipeline", action="store_true", help="synthesis A/B: the reference's sequential per-batch loop instead of "
+                    "utils.SynthPipeline (two streams)")
     ap.add_argument("--no-fuse-resblocks", action="store_true", help="synthesis A/B: HiFi-GAN's narrow-stage residual blocks as six launches "
                                                                       "each (the round-4 path) instead of one fused launch")
     ap.add_argument("--cpu-threads", default="8,16,32,64", help="torch thread counts the CPU baseline sweeps (those <= cpu_count)")
@@ -356,16 +358,28 @@ def synth_measure(args, device, rank, world, steps, warmup, want_roofline):
             wavs = utils.synth_samples(batch, out, voc, mcfg, pcfg, None, write=False)   # includes the D2H of the PCM
         return out, wavs
 
-    for i in range(warmup):
-        step(i)
+    # the product's loop (synthesize.synthesize): utils.SynthPipeline - batch i+1's acoustic model on one stream under batch i's
+    # vocoder on another, PCM to the host behind an event; --no-synth-pipeline: the reference's sequential loop (A/B)
+    pipe = None if args.no_synth_pipeline else utils.SynthPipeline(model, voc, (pcfg, mcfg), device=device)
+
+    def run(n):
+        """n batches through the loop under test; yields each batch's host PCM list (in order)"""
+        if pipe is None:
+            for i in range(n):
+                yield step(i)[1]
+        else:
+            for _batch, _out, wavs in pipe(batches[i % len(batches)] for i in range(n)):
+                yield wavs
+
+    for _ in run(warmup):
+        pass
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
     audio_samples, frames = 0, 0
     t0 = time.perf_counter()
-    for i in range(steps):
-        out, wavs = step(i)
+    for wavs in run(steps):                                     # (fill and drain of the pipeline are inside the timed region)
         audio_samples += sum(len(w) for w in wavs)            # (host lists: the PCM is already on the host)
         frames += int(sum(len(w) for w in wavs)) // 256
     torch.cuda.synchronize()
@@ -373,7 +387,9 @@ def synth_measure(args, device, rank, world, steps, warmup, want_roofline):
         dist.barrier()
     dt = time.perf_counter() - t0
     res = {"dt": dt, "audio_s": audio_samples / 22050.0, "frames": float(frames), "n_batches": len(batches),
-           "first_batch": groups[0]}
+           "first_batch": groups[0],
+           "loop": "sequential (synthesize.py:87-103)" if pipe is None else
+                   "utils.SynthPipeline: two streams, acoustic model of batch i+1 under the vocoder of batch i"}
     if want_roofline:
         # instrumented replay: HIP events around every conv_gemm launch of the acoustic model + vocoder (one stream), over
         # every 8th batch of the pass
@@ -440,7 +456,7 @@ def synth_main(args):
             "dtype": f"{args.dtype} acoustic / {args.vocoder_dtype} vocoder", "data": "synthetic",
             "config": {"workload": synth_workload_text(args),
                        "audio_s_per_step": round(audio_s / args.steps / world, 2), "mel_frames_per_s": round(frames / dt, 1),
-                       "x_realtime": round(audio_s / dt, 1), "library": lib_used, "dev_env": []},
+                       "x_realtime": round(audio_s / dt, 1), "loop": r["loop"], "library": lib_used, "dev_env": []},
             "roofline": r.get("roofline"), "cpu_baseline": cpu}))
     if dist.is_initialized():
         dist.barrier()                     # ranks leave together (rank 0 was still replaying for the roofline)
@@ -776,7 +792,7 @@ def main():
                  "ms_per_step": round(r["dt"] / 64 * 1e3, 3), "mel_frames_per_s": round(r["frames"] / r["dt"], 1),
                  "x_realtime": round(r["audio_s"] / r["dt"], 1), "audio_s": round(r["audio_s"], 1),
                  "dtype": f"{args.dtype} acoustic / {args.vocoder_dtype} vocoder", "workload": synth_workload_text(args),
-                 "roofline": r.get("roofline")}
+                 "loop": r["loop"], "roofline": r.get("roofline")}
         if not args.no_cpu_baseline:
             synth["cpu_baseline"] = synth_cpu_baseline(args, r["first_batch"], cpu["cores"] if cpu else min(_thread_counts(args)[-1], 32))
 

@@ -1037,6 +1037,16 @@ extern "C" int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens,
     return conv_gemm_pick(a, dtype, has_map != 0).variant;
 }
 
+// the same query for a fs2_conv_gemm_lrelu_io launch (stored-leaky-ReLU chains: their dispatch also depends on the epilogue operands)
+extern "C" int fs2_conv_gemm_lrelu_io_variant(long ldx, long ldy, long ldr, int accumulate, int M, int N, int Cin, int S, int taps, int dil,
+                                              int act, float res_unlrelu, float post_slope, int dtype) {
+    ConvGemmArgs a;
+    conv_gemm_fill(a, nullptr, ldx, nullptr, nullptr, ldr ? (const void*)16 : nullptr, ldr, nullptr, ldy, nullptr, M, N, Cin, S > 0 ? S : 1,
+                   taps, dil, 0, act, 0.f, FS2_ACT_NONE, 0.f, accumulate, 1.f, dtype);
+    a.res_unlrelu = res_unlrelu; a.post_slope = post_slope;
+    return conv_gemm_pick(a, dtype, false).variant;
+}
+
 static int conv_gemm_impl(const void* X, long ldx, const void* W, const float* bias, const void* R, long ldr, void* Y,
                           long ldy, const int32_t* lens, const int32_t* tile_map, float* tail_ws, int M, int N, int Cin, int S, int taps,
                           int dil, int pad, int act, float slope, int in_act, float in_slope, int accumulate, float out_scale,

@@ -653,14 +653,20 @@ class Engine:
             dur = ops.duration_round(logd, d_control)
             st.d_rounded = dur
             T = st.max_mel_len
+        ml_host = None
         if T is None:
-            # inference: output length = longest expanded sequence (host sync, as utils/tools.py:93-94 does)
+            # inference: output length = longest expanded sequence (host sync, as utils/tools.py:93-94 does).  The whole vector
+            # comes back in that one round trip and rides on the returned mel_lens (`_fs2_host`): synth_samples cuts the PCM by it
+            # without a second synchronisation
             cum, _, mel_len = ops.lr_index(dur, 1)
-            T = max(int(mel_len.max().item()), 1)
+            ml_host = mel_len.cpu().numpy()
+            T = max(int(ml_host.max()), 1)
         # decoder truncation (transformer/Models.py:145-162)
         Tdec = T if ((not training) and T > self.max_seq_len) else min(T, self.max_seq_len)
         cum, idx, mel_len = ops.lr_index(dur, Tdec)
         st.mel_lens_out, st.Tdec = mel_len, Tdec
+        if ml_host is not None:
+            mel_len._fs2_host = ml_host
         dec_lens32, st.mel_masks, dec_lens32._fs2_tmap = ops.lens_prep(mel_len, B, Tdec, st.counts[1:2])
         # (training: the frame counts equal the batch's mel_lens - sum of the target durations - whose host copy came with the batch)
         dec_lens32._fs2_skip = self._skip_fraction(((hint[1] if hint and hint[1] is not None else getattr(st.mel_lens, "_fs2_host", None))

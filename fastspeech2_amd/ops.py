@@ -129,9 +129,13 @@ def conv_gemm(x, wpacked, bias, S, taps=1, dil=1, pad=0, act=ACT_NONE, slope=0.0
                   taps, dil, pad, act, slope, in_act, in_slope, int(accumulate), out_scale, dt(x), _stream())
     if PROFILE is not None:
         e1.record()
-        var = 5 if ksplit > 1 and taps > 1 else (6 if ksplit > 1 else
-              _lib.load().fs2_conv_gemm_variant(ldx, ldy, ldr, int(lens is not None), int(tmap is not None), M, N, Cin, S, taps, dil,
-                                                in_act, in_slope, dt(x)))
+        if res_unlrelu or post_slope:
+            var = _lib.load().fs2_conv_gemm_lrelu_io_variant(ldx, ldy, ldr, int(accumulate), M, N, Cin, S, taps, dil, act, res_unlrelu,
+                                                             post_slope, dt(x))
+        else:
+            var = 5 if ksplit > 1 and taps > 1 else (6 if ksplit > 1 else
+                  _lib.load().fs2_conv_gemm_variant(ldx, ldy, ldr, int(lens is not None), int(tmap is not None), M, N, Cin, S, taps, dil,
+                                                    in_act, in_slope, dt(x)))
         PROFILE.setdefault("conv_gemm", []).append((2.0 * M * N * Cin * taps, e0, e1, var, (lens is not None) or bool(ragged), S))
     return out
 

@@ -168,18 +168,87 @@ def pad_2D(inputs, maxlen=None):
 def synth_samples(targets, predictions, vocoder, model_config, preprocess_config, path, write=True):
     """utils/tools.py:164-198 without the matplotlib figures: vocode the post-net mels of a synth batch and write
     `{path}/{basename}.wav`.  Returns the list of int16 arrays."""
-    from scipy.io import wavfile
-
     basenames = targets[0]
     mel_predictions = predictions[1].transpose(1, 2)                     # (B, 80, T) view — zero-copy into the vocoder
-    lengths = predictions[9] * preprocess_config["preprocessing"]["stft"]["hop_length"]
+    lengths = _sample_lengths(predictions[9], preprocess_config)
     wavs = vocoder_infer(mel_predictions, vocoder, model_config, preprocess_config, lengths=lengths)
     if write:
-        os.makedirs(path, exist_ok=True)
-        sr = preprocess_config["preprocessing"]["audio"]["sampling_rate"]
-        for wav, basename in zip(wavs, basenames):
-            wavfile.write(os.path.join(path, "{}.wav".format(basename)), sr, wav)
+        _write_wavs(path, basenames, wavs, preprocess_config)
     return wavs
+
+
+def _sample_lengths(mel_lens, preprocess_config):
+    """frames -> samples per utterance (utils/tools.py:176); from the host copy the engine's own length round trip left on the
+    tensor when there is one (no second synchronisation), else from the tensor."""
+    hop = preprocess_config["preprocessing"]["stft"]["hop_length"]
+    host = getattr(mel_lens, "_fs2_host", None)
+    return [int(n) * hop for n in host] if host is not None else (mel_lens * hop).tolist()
+
+
+def _write_wavs(path, basenames, wavs, preprocess_config):
+    from scipy.io import wavfile
+    os.makedirs(path, exist_ok=True)
+    sr = preprocess_config["preprocessing"]["audio"]["sampling_rate"]
+    for wav, basename in zip(wavs, basenames):
+        wavfile.write(os.path.join(path, "{}.wav".format(basename)), sr, wav)
+
+
+class SynthPipeline:
+    """Batch synthesis (synthesize.py:87-103: model -> synth_samples, one batch after the other) as a two-stage pipeline on two HIP
+    streams.  The acoustic model of batch i+1 - ~150 short launches around a host round trip for the output length - is issued on
+    a high-priority stream while HiFi-GAN still works on batch i on another; the PCM of batch i comes back through pinned memory
+    behind an event, and the host only waits for it AFTER batch i+1's launches are queued, so the device never drains between
+    batches.  Per batch the launches, their order and their operands are those of the sequential loop: the samples are
+    bit-identical (tests/test_synth_pipeline_gpu.py).
+
+    for batch, output, wavs in SynthPipeline(model, vocoder, configs)(batches): ...   # in batch order, one batch behind"""
+
+    def __init__(self, model, vocoder, configs, control_values=(1.0, 1.0, 1.0), device=None, path=None, write=False):
+        self.model, self.vocoder = model, vocoder
+        self.preprocess_config, self.model_config = configs[0], configs[1]
+        assert self.model_config["vocoder"]["model"] == "HiFi-GAN"
+        self.controls = control_values
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.path, self.write = path, write
+        self.s_ac = torch.cuda.Stream(device=self.device, priority=-1)
+        self.s_voc = torch.cuda.Stream(device=self.device)
+
+    def _launch(self, batch):
+        p, e, d = self.controls
+        self.s_ac.wait_stream(torch.cuda.current_stream(self.device))     # the batch's host-to-device copies
+        with torch.no_grad():
+            with torch.cuda.stream(self.s_ac):
+                out = self.model(*(batch[2:]), p_control=p, e_control=e, d_control=d)
+                lengths = _sample_lengths(out[9], self.preprocess_config)
+                ready = torch.cuda.Event()
+                ready.record(self.s_ac)
+            with torch.cuda.stream(self.s_voc):
+                self.s_voc.wait_event(ready)
+                pcm = self.vocoder.infer_pcm(out[1].transpose(1, 2), self.preprocess_config["preprocessing"]["audio"]["max_wav_value"])
+                host = torch.empty(pcm.shape, dtype=pcm.dtype, pin_memory=True)
+                host.copy_(pcm, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.s_voc)
+        # `out` and `pcm` were allocated on one stream and are read on another: they stay referenced until `done` has been waited for
+        return batch, out, pcm, host, lengths, done
+
+    def _finish(self, item):
+        batch, out, pcm, host, lengths, done = item
+        done.synchronize()
+        wavs = [w[:n] for w, n in zip(host.numpy(), lengths)]
+        if self.write:
+            _write_wavs(self.path, batch[0], wavs, self.preprocess_config)
+        return batch, out, wavs
+
+    def __call__(self, batches):
+        prev = None
+        for batch in batches:
+            cur = self._launch(batch)
+            if prev is not None:
+                yield self._finish(prev)
+            prev = cur
+        if prev is not None:
+            yield self._finish(prev)
 
 
 def synth_one_sample(targets, predictions, vocoder, model_config, preprocess_config):

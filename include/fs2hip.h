@@ -104,6 +104,10 @@ int fs2_ldsdma_calibrate(const void* src, size_t src_bytes, int iters, float* si
 #define FS2_GEMM_STREAM_K256 9 /* conv_gemm_s_kernel: one tap, K = 256, N % 256 == 0 - weights in registers, X streamed through LDS (HBM-bound) */
 int fs2_conv_gemm_variant(long ldx, long ldy, long ldr, int has_lens, int has_map, int M, int N, int Cin, int S, int taps,
                           int dil, int in_act, float in_slope, int dtype);
+/* ... and of a fs2_conv_gemm_lrelu_io launch (its dispatch also looks at the epilogue operands: residual / accumulate launches with
+ * a short reduction go to the ring kernel's LDS-staged epilogue) */
+int fs2_conv_gemm_lrelu_io_variant(long ldx, long ldy, long ldr, int accumulate, int M, int N, int Cin, int S, int taps, int dil,
+                                   int act, float res_unlrelu, float post_slope, int dtype);
 /* Master conv weights are stored tap-major W[n][j][c] f32 (the (Cout,Cin,k) nn.Parameter is a permuted view of it):
  * -> Wf[n][j][c] (forward: dtype cast) and/or Wd[c][j][n] = W[n][k-1-j][c] (data gradient: tap flip + transpose). */
 int fs2_pack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int k, int dtype, fs2_stream_t stream);

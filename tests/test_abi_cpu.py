@@ -59,3 +59,18 @@ def test_product_forward_refuses_cpu_tensors():
     m = FastSpeech2(pcfg, mcfg)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, dtype=torch.long), torch.ones(1, 4, dtype=torch.long), torch.tensor([4]), 4)
+
+
+def test_dispatch_queries_are_pure_host_functions():
+    """fs2_conv_gemm_variant / fs2_conv_gemm_lrelu_io_variant answer without a device (bench.py attributes its HIP-event durations
+    to kernel names with them): HiFi-GAN's stored-leaky-ReLU launches with a residual / accumulate operand and a short reduction
+    go to the ring kernel (3), the same shapes without one to the persistent kernel (5); the FFN convolution stays on 5."""
+    lib = _lib.load()
+    BF16 = 1
+    for (B, S, C, k) in [(4, 12000, 128, 7), (8, 5600, 256, 11), (4, 12000, 128, 3)]:
+        M = B * S
+        assert lib.fs2_conv_gemm_lrelu_io_variant(C, C, C, 0, M, C, C, S, k, 1, 0, 10.0, 0.1, BF16) == 3
+        assert lib.fs2_conv_gemm_lrelu_io_variant(C, C, 0, 1, M, C, C, S, k, 1, 0, 0.0, 0.1, BF16) == 3
+        assert lib.fs2_conv_gemm_lrelu_io_variant(C, C, 0, 0, M, C, C, S, k, 1, 0, 0.0, 0.1, BF16) == 5
+    assert lib.fs2_conv_gemm_variant(256, 1024, 0, 0, 0, 48 * 925, 1024, 256, 925, 9, 1, 0, 0.0, BF16) == 5
+    assert lib.fs2_conv_gemm_variant(256, 768, 0, 0, 0, 48 * 925, 768, 256, 925, 1, 1, 0, 0.0, BF16) == 9
