@@ -24,10 +24,11 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import fastspeech2_amd  # noqa: E402,F401  (before the first HIP call: the package sets the process's HIP hardware-queue default)
+
+import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
 TRAIN_FLOP_PER_FRAME = 117.5e6                         # 3 x 39.17 MFLOP fwd (4+4, phoneme-level)
@@ -71,8 +72,9 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph-line", action="store_true", help="skip the hipGraph replay of the same step reported beside the eager number")
     ap.add_argument("--no-synth", action="store_true", help="train mode: skip the batch-synthesis RTF object (config.synth)")
+    ap.add_argument("--synth-voc-streams", type=int, default=3, help="synthesis A/B: vocoder streams of utils.SynthPipeline (its default: 3)")
     ap.add_argument("--no-synth-pipeline", action="store_true", help="synthesis A/B: the reference's sequential per-batch loop instead of "
-                    "utils.SynthPipeline (two streams)")
+                    "utils.SynthPipeline")
     ap.add_argument("--no-fuse-resblocks", action="store_true", help="synthesis A/B: HiFi-GAN's narrow-stage residual blocks as six launches "
                                                                       "each (the round-4 path) instead of one fused launch")
     ap.add_argument("--cpu-threads", default="8,16,32,64", help="torch thread counts the CPU baseline sweeps (those <= cpu_count)")
@@ -360,7 +362,7 @@ def synth_measure(args, device, rank, world, steps, warmup, want_roofline):
 
     # the product's loop (synthesize.synthesize): utils.SynthPipeline - batch i+1's acoustic model on one stream under batch i's
     # vocoder on another, PCM to the host behind an event; --no-synth-pipeline: the reference's sequential loop (A/B)
-    pipe = None if args.no_synth_pipeline else utils.SynthPipeline(model, voc, (pcfg, mcfg), device=device)
+    pipe = None if args.no_synth_pipeline else utils.SynthPipeline(model, voc, (pcfg, mcfg), device=device, voc_streams=args.synth_voc_streams)
 
     def run(n):
         """n batches through the loop under test; yields each batch's host PCM list (in order)"""
@@ -389,7 +391,8 @@ def synth_measure(args, device, rank, world, steps, warmup, want_roofline):
     res = {"dt": dt, "audio_s": audio_samples / 22050.0, "frames": float(frames), "n_batches": len(batches),
            "first_batch": groups[0],
            "loop": "sequential (synthesize.py:87-103)" if pipe is None else
-                   "utils.SynthPipeline: two streams, acoustic model of batch i+1 under the vocoder of batch i"}
+                   f"utils.SynthPipeline: acoustic model of the next batch on one stream under the vocoders of the previous "
+                   f"{args.synth_voc_streams} on {args.synth_voc_streams} more"}
     if want_roofline:
         # instrumented replay: HIP events around every conv_gemm launch of the acoustic model + vocoder (one stream), over
         # every 8th batch of the pass

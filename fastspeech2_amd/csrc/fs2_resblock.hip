@@ -280,7 +280,11 @@ __global__ void __launch_bounds__(512, 2) resblock_fused_kernel(ResBlockArgs a) 
     };
     for (int j = 0; j < a.nblk; ++j) {
         load_rows(X, a.ldx, y);                // y <- x (blocks after the first: from L2)
-        if (j > 0) rb_barrier_lds();           // every wave has finished the previous block's last convolution
+        // every wave has finished the previous block's last convolution; first block: the bias table (written by whichever threads own
+        // its entries) is complete before any wave's first convolution reads it - run_conv reads the biases BEFORE its first group
+        // barrier, and without this one a fast wave could pick up what the previous launch left in LDS (seen once in ~1000 launches as
+        // an error of the size of a bias: profiles/r05zzz_pytest_flake.log)
+        rb_barrier_lds();
         write_act(y);
         for (int m = 0; m < 3; ++m) {
             run_conv(t_acc, j, 2 * m, false);

@@ -194,16 +194,18 @@ def _write_wavs(path, basenames, wavs, preprocess_config):
 
 
 class SynthPipeline:
-    """Batch synthesis (synthesize.py:87-103: model -> synth_samples, one batch after the other) as a two-stage pipeline on two HIP
+    """Batch synthesis (synthesize.py:87-103: model -> synth_samples, one batch after the other) as a two-stage pipeline on HIP
     streams.  The acoustic model of batch i+1 - ~150 short launches around a host round trip for the output length - is issued on
     a high-priority stream while HiFi-GAN still works on batch i on another; the PCM of batch i comes back through pinned memory
-    behind an event, and the host only waits for it AFTER batch i+1's launches are queued, so the device never drains between
-    batches.  Per batch the launches, their order and their operands are those of the sequential loop: the samples are
-    bit-identical (tests/test_synth_pipeline_gpu.py).
+    behind an event, and the host only waits for it AFTER the next batches' launches are queued, so the device never drains between
+    batches.  Consecutive batches' vocoders go to `voc_streams` alternating streams: every HiFi-GAN launch ends in a partial round
+    of tiles, and the other batch's launch fills it (same box, ms per val.txt-shaped batch of 8: sequential 7.05, one vocoder
+    stream 5.88 - 5.96, two 5.16, three 5.07: profiles/r05w_*, r05x_*).  Per batch the launches, their order and their operands are
+    those of the sequential loop: the samples are bit-identical (tests/test_vocoder_stft_gpu.py::test_synth_pipeline_*).
 
-    for batch, output, wavs in SynthPipeline(model, vocoder, configs)(batches): ...   # in batch order, one batch behind"""
+    for batch, output, wavs in SynthPipeline(model, vocoder, configs)(batches): ...   # in batch order, `voc_streams` batches behind"""
 
-    def __init__(self, model, vocoder, configs, control_values=(1.0, 1.0, 1.0), device=None, path=None, write=False):
+    def __init__(self, model, vocoder, configs, control_values=(1.0, 1.0, 1.0), device=None, path=None, write=False, voc_streams=3):
         self.model, self.vocoder = model, vocoder
         self.preprocess_config, self.model_config = configs[0], configs[1]
         assert self.model_config["vocoder"]["model"] == "HiFi-GAN"
@@ -211,7 +213,9 @@ class SynthPipeline:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.path, self.write = path, write
         self.s_ac = torch.cuda.Stream(device=self.device, priority=-1)
-        self.s_voc = torch.cuda.Stream(device=self.device)
+        # voc_streams > 1: consecutive batches' vocoders on alternating streams (the tail of one launch filled by the other batch's)
+        self.s_vocs = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(voc_streams)))]
+        self._n = 0
 
     def _launch(self, batch):
         p, e, d = self.controls
@@ -222,13 +226,15 @@ class SynthPipeline:
                 lengths = _sample_lengths(out[9], self.preprocess_config)
                 ready = torch.cuda.Event()
                 ready.record(self.s_ac)
-            with torch.cuda.stream(self.s_voc):
-                self.s_voc.wait_event(ready)
+            s_voc = self.s_vocs[self._n % len(self.s_vocs)]
+            self._n += 1
+            with torch.cuda.stream(s_voc):
+                s_voc.wait_event(ready)
                 pcm = self.vocoder.infer_pcm(out[1].transpose(1, 2), self.preprocess_config["preprocessing"]["audio"]["max_wav_value"])
                 host = torch.empty(pcm.shape, dtype=pcm.dtype, pin_memory=True)
                 host.copy_(pcm, non_blocking=True)
                 done = torch.cuda.Event()
-                done.record(self.s_voc)
+                done.record(s_voc)
         # `out` and `pcm` were allocated on one stream and are read on another: they stay referenced until `done` has been waited for
         return batch, out, pcm, host, lengths, done
 
@@ -241,14 +247,13 @@ class SynthPipeline:
         return batch, out, wavs
 
     def __call__(self, batches):
-        prev = None
+        flight = []
         for batch in batches:
-            cur = self._launch(batch)
-            if prev is not None:
-                yield self._finish(prev)
-            prev = cur
-        if prev is not None:
-            yield self._finish(prev)
+            flight.append(self._launch(batch))
+            while len(flight) > len(self.s_vocs):
+                yield self._finish(flight.pop(0))
+        while flight:
+            yield self._finish(flight.pop(0))
 
 
 def synth_one_sample(targets, predictions, vocoder, model_config, preprocess_config):

@@ -29,7 +29,7 @@ def synthesize(model, step, configs, vocoder, batchs, control_values, device=Non
     pitch_control, energy_control, duration_control = control_values
     device = device or torch.device("cuda", torch.cuda.current_device())
     n = 0
-    # the reference's loop (synthesize.py:87-103) as a two-stream pipeline: batch i+1's acoustic model under batch i's vocoder
+    # the reference's loop (synthesize.py:87-103) as a stream pipeline: the next batch's acoustic model under the previous batches' vocoders
     pipeline = SynthPipeline(model, vocoder, configs, control_values, device=device, path=train_config["path"]["result_path"],
                              write=True)
     for batch, _output, _wavs in pipeline(DevicePrefetcher(batchs, device)):

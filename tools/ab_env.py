@@ -53,7 +53,8 @@ if __name__ == "__main__":
         one(); sys.exit(0)
     for r in range(2):
         for setting in sys.argv[1:]:
-            e = dict(os.environ, FS2_LIB_PATH=os.path.join(ROOT, "fastspeech2_amd", "libfs2hip_dev.so"))
+            devlib = os.path.join(ROOT, "fastspeech2_amd", "libfs2hip_dev.so")        # (absent: the shipped library - runtime variables only)
+            e = dict(os.environ, FS2_LIB_PATH=devlib if os.path.exists(devlib) else os.path.join(ROOT, "fastspeech2_amd", "libfs2hip.so"))
             e.update(dict(kv.split("=") for kv in setting.split(",") if kv))
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=e, capture_output=True, text=True, timeout=300)
             ms = [l for l in p.stdout.splitlines() if l.startswith("MS ")]
