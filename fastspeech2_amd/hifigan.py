@@ -179,6 +179,11 @@ class Generator(nn.Module):
         self._packed = (key, W)
         return W
 
+    def prepare(self, device):
+        """pack the kernels' weight images for `device` now, on the current stream (they are otherwise packed by the first forward, on
+        whatever stream that runs on: a caller that spreads forwards over several streams - utils.SynthPipeline - orders them behind this)"""
+        self._weights(torch.device(device))
+
     # ------------------------------------------------------------------ forward
     def _run(self, x_rows, B, T, want_wav, want_pcm, max_wav_value):
         """x_rows: [B*T][80] in the compute dtype.  Returns (wav f32 (B, T*hop) | None, pcm int16 (B, T*hop) | None).

@@ -216,6 +216,13 @@ class SynthPipeline:
         # voc_streams > 1: consecutive batches' vocoders on alternating streams (the tail of one launch filled by the other batch's)
         self.s_vocs = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(voc_streams)))]
         self._n = 0
+        # the vocoder's packed weight images: made once, here, and every stream of the pipeline is ordered behind that (the first
+        # forward would otherwise pack them on ITS stream while the next batch's forward reads them on another)
+        vocoder.prepare(self.device)
+        packed = torch.cuda.Event()
+        packed.record(torch.cuda.current_stream(self.device))
+        for st in [self.s_ac] + self.s_vocs:
+            st.wait_event(packed)
 
     def _launch(self, batch):
         p, e, d = self.controls
@@ -248,12 +255,20 @@ class SynthPipeline:
 
     def __call__(self, batches):
         flight = []
-        for batch in batches:
-            flight.append(self._launch(batch))
-            while len(flight) > len(self.s_vocs):
+        try:
+            for batch in batches:
+                flight.append(self._launch(batch))
+                while len(flight) > len(self.s_vocs):
+                    yield self._finish(flight.pop(0))
+            while flight:
                 yield self._finish(flight.pop(0))
-        while flight:
-            yield self._finish(flight.pop(0))
+        finally:
+            # the consumer stopped early (or a launch raised): the batches still in flight read tensors of one stream's pool on another -
+            # nothing may be released before their work has finished
+            for item in flight:
+                item[-1].synchronize()
+            if flight:
+                self.s_ac.synchronize()
 
 
 def synth_one_sample(targets, predictions, vocoder, model_config, preprocess_config):
