@@ -94,7 +94,7 @@ int fs2_ldsdma_calibrate(const void* src, size_t src_bytes, int iters, float* si
  * lens / tile_map would be non-NULL; ldr = 0 without a residual operand. */
 #define FS2_GEMM_PLAIN 1   /* conv_gemm_kernel: 128x128 register-staged */
 #define FS2_GEMM_DMA 2     /* conv_gemm_dma_kernel: 128x128 LDS-DMA, halo reuse (incl. in-workgroup split-K) */
-#define FS2_GEMM_RING 3    /* conv_gemm_ring_kernel: 256x128 wave-specialised */
+#define FS2_GEMM_RING 3    /* conv_gemm_ring_kernel: 256x128 wave-specialised (shapes the persistent kernel declines; lrelu_io launches with a residual) */
 #define FS2_GEMM_SKINNY 4  /* conv_skinny_kernel: C = 32 / 64 */
 #define FS2_GEMM_PERSIST 5 /* conv_gemm_p_kernel<false>: persistent 256x128 convolution (taps >= 3), MFMA-bound */
 #define FS2_GEMM_PERSIST_1TAP 6 /* conv_gemm_p_kernel<true>: the same kernel for taps == 1 (Linear / k=1 conv): HBM-bound at K <= 1024 */
