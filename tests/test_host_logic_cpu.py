@@ -204,3 +204,17 @@ def test_committed_pmc_traffic_file_was_measured_on_the_current_contraction_sour
         f"its *_pmc_traffic.json")
     # and the file names the kernel the roofline line is about
     assert any(k.startswith("conv_gemm_p_kernel<false") for k in doc["kernels"])
+
+
+def test_sample_lengths_use_the_host_copy_when_the_engine_left_one():
+    """utils._sample_lengths (utils/tools.py:176: frames x hop_length): from the `_fs2_host` vector the engine's own length round trip
+    leaves on the returned mel_lens, else from the tensor - the same numbers either way."""
+    import numpy as np
+    import torch
+    from fastspeech2_amd.utils import _sample_lengths
+    pcfg = {"preprocessing": {"stft": {"hop_length": 256}}}
+    t = torch.tensor([7, 0, 925], dtype=torch.int64)
+    assert _sample_lengths(t, pcfg) == [1792, 0, 236800]
+    t._fs2_host = np.array([7, 0, 925], dtype=np.int64)
+    out = _sample_lengths(t, pcfg)
+    assert out == [1792, 0, 236800] and all(type(n) is int for n in out)
