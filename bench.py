@@ -26,7 +26,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import fastspeech2_amd  # noqa: E402,F401  (before the first HIP call: the package sets the process's HIP hardware-queue default)
+import fastspeech2_amd  # noqa: E402  (main() calls configure_hw_queues() before the first HIP call - importing changes nothing)
 
 import torch  # noqa: E402
 
@@ -53,6 +53,11 @@ def parse(argv=None):
     ap.add_argument("--workload", default="ljspeech", choices=["ljspeech", "libritts"],
                     help="ljspeech: BASELINE configs[1] (the reported metric).  libritts: configs[3]'s shape per GPU - multi-speaker "
                          "(2456-way speaker embedding), LibriTTS-like phoneme counts (median ~49, p95 ~176), length-bucketed batch")
+    ap.add_argument("--group-size", type=int, default=4,
+                    help="libritts: sorting window of the BucketedBatchSampler in steps (window = group_size x world x batch items; 4 = the "
+                         "reference's `group_size` in train.py:30-37, the compatibility default; wider windows leave less padding per batch)")
+    ap.add_argument("--libri-step", type=float, default=1.0 / 3,
+                    help="libritts: which step of the epoch is the measured batch, as a fraction of the epoch (default: the step a third in)")
     ap.add_argument("--main-prio", type=int, default=-1,
                     help="priority of the stream the step runs on (-1 = high: the dispatcher prefers the critical fwd/dgrad chain over "
                          "the side stream's weight gradients; 0 = run on the default stream)")
@@ -77,6 +82,9 @@ def parse(argv=None):
                     "utils.SynthPipeline")
     ap.add_argument("--no-fuse-resblocks", action="store_true", help="synthesis A/B: HiFi-GAN's narrow-stage residual blocks as six launches "
                                                                       "each (the round-4 path) instead of one fused launch")
+    ap.add_argument("--hw-queues", type=int, default=fastspeech2_amd.HW_QUEUES_DEFAULT,
+                    help="GPU_MAX_HW_QUEUES of every rank (fastspeech2_amd.configure_hw_queues: the SAME at every --gpus N, so the N-rank "
+                         "line is the configuration the one-rank line was measured on; an exported value wins; 0 = runtime default)")
     ap.add_argument("--cpu-threads", default="8,16,32,64", help="torch thread counts the CPU baseline sweeps (those <= cpu_count)")
     a = ap.parse_args(argv)
     argv = sys.argv if argv is None else argv
@@ -128,9 +136,9 @@ def build(args, device, rank, world, dtype=None):
         from fastspeech2_amd.data import BucketedBatchSampler
         g = torch.Generator().manual_seed(99)
         pool = torch.clamp(torch.exp(torch.randn(8192, generator=g) * 0.78 + 3.89), 5, 250).long()
-        sampler = BucketedBatchSampler(pool.numpy(), args.batch, world_size=world, rank=rank, group_size=4, shuffle=True, seed=1234)
+        sampler = BucketedBatchSampler(pool.numpy(), args.batch, world_size=world, rank=rank, group_size=args.group_size, shuffle=True, seed=1234)
         steps = list(iter(sampler))
-        idxs = steps[len(steps) // 3]                        # one fixed step of the epoch (every rank picks the same step)
+        idxs = steps[min(len(steps) - 1, int(len(steps) * args.libri_step))]    # one fixed step of the epoch (every rank picks the same step)
         b = synthetic_batch(1234 + rank, 0, 0, dur_lo=4, dur_hi=10, n_speaker=2456, src_lens=pool[idxs].tolist())
     else:
         # every rank gets the SAME length profile (what the length-bucketed card-wise sampler of fastspeech2_amd/data.py deals
@@ -459,7 +467,8 @@ def synth_main(args):
             "dtype": f"{args.dtype} acoustic / {args.vocoder_dtype} vocoder", "data": "synthetic",
             "config": {"workload": synth_workload_text(args),
                        "audio_s_per_step": round(audio_s / args.steps / world, 2), "mel_frames_per_s": round(frames / dt, 1),
-                       "x_realtime": round(audio_s / dt, 1), "loop": r["loop"], "library": lib_used, "dev_env": []},
+                       "x_realtime": round(audio_s / dt, 1), "loop": r["loop"], "library": lib_used, "dev_env": [],
+                       "hw_queues": dict(fastspeech2_amd.HW_QUEUES)},
             "roofline": r.get("roofline"), "cpu_baseline": cpu}))
     if dist.is_initialized():
         dist.barrier()                     # ranks leave together (rank 0 was still replaying for the roofline)
@@ -536,6 +545,9 @@ def pmc_traffic(kernel_substr):
 
 def main():
     args = parse()
+    # first thing, before any HIP call and before the self-launch (whose ranks inherit the exported value): one hardware-queue
+    # setting for every world size - recorded in the line as config.hw_queues
+    fastspeech2_amd.configure_hw_queues(args.hw_queues)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
     if args.mode == "synth":
@@ -647,7 +659,11 @@ def main():
         allm = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allm, mine)
         ms = [float(x[0]) for x in allm]
+        # the three numbers an N-rank line is read for: the slowest rank's LOCAL step (what the job cannot beat), the
+        # data-parallel step next to it - their difference is what the exchange + the count all-reduce + the barrier skew cost on
+        # top, i.e. the part of the gradient exchange that backward did not hide - and the spread of the ranks' local steps
         dist_info.update({"per_rank_local_ms": [round(x, 3) for x in ms], "slowest_over_fastest": round(max(ms) / min(ms), 3),
+                          "exchange_exposed_ms": round(dt / args.steps * 1e3 - max(ms), 3),
                           "per_rank_T": [int(x[1]) for x in allm], "per_rank_L": [int(x[2]) for x in allm],
                           "per_rank_frames": [int(x[3]) for x in allm]})
 
@@ -796,6 +812,17 @@ def main():
                  "x_realtime": round(r["audio_s"] / r["dt"], 1), "audio_s": round(r["audio_s"], 1),
                  "dtype": f"{args.dtype} acoustic / {args.vocoder_dtype} vocoder", "workload": synth_workload_text(args),
                  "loop": r["loop"], "roofline": r.get("roofline")}
+        if not args.no_fp32:
+            # config 5 in the REFERENCE's own arithmetic (utils/model.py:74-92 and synthesize.py run fp32): fp32 acoustic model + fp32
+            # vocoder on the same 64 batches through the same loop (exact-f32 MFMA, 157.3 TF roof; the fused ResBlock stage kernel is
+            # bf16-only, so this is also the un-fused pass) - the number a lower-precision RTF has to be read beside
+            import copy
+            a32 = copy.copy(args)
+            a32.dtype, a32.vocoder_dtype = "fp32", "fp32"
+            r32 = synth_measure(a32, device, 0, 1, 64, 8, False)
+            synth.update({"fp32_rtf": round(r32["dt"] / r32["audio_s"], 6), "fp32_ms_per_step": round(r32["dt"] / 64 * 1e3, 3),
+                          "fp32_x_realtime": round(r32["audio_s"] / r32["dt"], 1), "fp32_dtype": "fp32 acoustic / fp32 vocoder",
+                          "fp32_frac_of_f32_peak": round(r32["frames"] / r32["dt"] * 614.1e6 / (MFMA_PEAK_TFLOPS["fp32"] * 1e12), 4)})
         if not args.no_cpu_baseline:
             synth["cpu_baseline"] = synth_cpu_baseline(args, r["first_batch"], cpu["cores"] if cpu else min(_thread_counts(args)[-1], 32))
 
@@ -835,11 +862,13 @@ def main():
                                    f"batch={args.batch}/GPU, L={b['max_src_len']} phonemes, T={b['max_mel_len']} frames, "
                                    "fwd+loss+bwd+clip+Adam, dropout on, fp32 master weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                       "valid_row_fraction": round(frames.item() / padded.item(), 4),
+                       **({"sampler_group_size": args.group_size} if args.workload == "libritts" else {}),
                        **({"hip_graph_ms_per_step": round(graph_ms, 3)} if graph_ms is not None else {}),
                        "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),
                        "side_stream_wgrad": bool(args.side_stream) and graph is None, **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
                        "windows": len(window_s), "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in window_s],
-                       "library": lib_used, "dev_env": [], **fp32, **dist_info, **({"synth": synth} if synth else {})},
+                       "library": lib_used, "dev_env": [], "hw_queues": dict(fastspeech2_amd.HW_QUEUES), **fp32, **dist_info, **({"synth": synth} if synth else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

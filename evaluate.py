@@ -12,6 +12,7 @@ import argparse
 import torch
 import yaml
 
+import fastspeech2_amd
 from fastspeech2_amd.data import Dataset, DevicePrefetcher
 from fastspeech2_amd.model import FastSpeech2Loss
 from fastspeech2_amd.utils import get_model, get_vocoder, synth_one_sample
@@ -58,6 +59,9 @@ def parse_args(argv=None):
     parser.add_argument("-m", "--model_config", type=str, required=True, help="path to model.yaml")
     parser.add_argument("-t", "--train_config", type=str, required=True, help="path to train.yaml")
     parser.add_argument("--dtype", default=None, choices=[None, "fp32", "bf16"], help="compute dtype of the HIP engine (default: FS2_DTYPE or fp32)")
+    parser.add_argument("--hw_queues", type=int, default=fastspeech2_amd.HW_QUEUES_DEFAULT,
+                        help="HIP hardware queues of this process (GPU_MAX_HW_QUEUES; the runtime default 4 makes streams share queues: "
+                             "utils.SynthPipeline / the engine's side streams); the same for every world size; an exported value wins; 0 = leave the runtime default")
     return parser.parse_args(argv)
 
 
@@ -68,6 +72,7 @@ def load_configs(args):
 
 if __name__ == "__main__":
     args = parse_args()
+    fastspeech2_amd.configure_hw_queues(args.hw_queues)       # before the first HIP call
     configs = load_configs(args)
     device = torch.device("cuda")
     model = get_model(args, configs, device, train=False, compute_dtype=args.dtype)

@@ -357,7 +357,8 @@ extern "C" int fs2_resblock_supported(int C, int k, int d0, int d1, int d2, int 
     if (dtype != FS2_BF16 || (C != 32 && C != 64) || k < 1 || k > 11 || !(k & 1)) return 0;
     if (d0 < 1 || d1 < 1 || d2 < 1) return 0;
     const int pad2 = (k - 1) / 2;
-    if (pad2 * (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) > 32) return 0;                 // a shifted read stays inside the guard rows
+    // a shifted read stays inside the guard rows: |shift| <= GUARD - 1 (the bound is the tile's own constant, so the two cannot drift)
+    if (pad2 * (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) > RbCfg<32>::GUARD - 1) return 0;
     const int E = C == 32 ? 1024 : 512;
     return E - 2 * rb_halo(k, d0, d1, d2) >= 64 ? 1 : 0;
 }

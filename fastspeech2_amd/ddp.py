@@ -23,7 +23,9 @@ class GradExchange:
                  tail_bytes=48 << 20, collectives=None):
         """`collectives`: None = issue the all-reduces whenever a process group exists - ALSO over a one-rank group (the identity
         reduction costs one small RCCL launch per bucket and keeps the one-rank run the same program as the N-rank run); without a
-        process group there is nothing to call and the exchange is a no-op.  False forces the no-op, True insists on a group.
+        process group there is nothing to call and the exchange is a no-op - unless world_size > 1, which raises here (replicas
+        that never exchange anything must not look like a training job).  False forces the no-op; True keeps the exchange active
+        whatever the process state (schedule inspection in the tests: the first real all_reduce raises without a group).
 
         Buckets are `bucket_bytes` except over the LAST `tail_bytes` of the flat buffer (the encoder's gradients, final only
         when backward ends), which travel in `tail_bucket_bytes` pieces (default bucket_bytes / 4): whatever is still in flight
@@ -38,8 +40,14 @@ class GradExchange:
         self.tail_elems = max(1, tb // flat_grad.element_size())
         self.tail_start = max(0, self.n - tail_bytes // flat_grad.element_size())
         have_pg = dist.is_available() and dist.is_initialized()
-        # world > 1 without a group stays "active": the first all_reduce then raises instead of silently training unsynchronised
-        self.active = (have_pg or self.world > 1) if collectives is None else bool(collectives)
+        if have_pg and self.world != dist.get_world_size(group):
+            # RCCL averages over the GROUP's size inside the collective, the gloo path divides by self.world: a caller-supplied
+            # world_size that differs from the group's would make the two backends disagree silently
+            raise ValueError(f"GradExchange: world_size={self.world} but the process group has {dist.get_world_size(group)} ranks")
+        if not have_pg and self.world > 1 and collectives is None:
+            raise RuntimeError(f"GradExchange: world_size={self.world} without an initialised process group - the replicas would "
+                               "train unsynchronised (call torch.distributed.init_process_group first)")
+        self.active = have_pg if collectives is None else bool(collectives)
         self.cuda = flat_grad.is_cuda
         self.overlap = overlap and self.cuda
         # RCCL averages inside the collective (ncclAvg): no scaling pass over the bucket.  gloo has no AVG: divide, then SUM

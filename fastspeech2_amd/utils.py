@@ -211,6 +211,8 @@ class SynthPipeline:
         assert self.model_config["vocoder"]["model"] == "HiFi-GAN"
         self.controls = control_values
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.index is None:          # "cuda" -> "cuda:N": the vocoder's weight images are cached per RESOLVED device, and a
+            self.device = torch.device("cuda", torch.cuda.current_device())   # miss would re-pack them on a vocoder stream mid-pipeline
         self.path, self.write = path, write
         self.s_ac = torch.cuda.Stream(device=self.device, priority=-1)
         # voc_streams > 1: consecutive batches' vocoders on alternating streams (the tail of one launch filled by the other batch's)
@@ -255,6 +257,7 @@ class SynthPipeline:
 
     def __call__(self, batches):
         flight = []
+        clean = False
         try:
             for batch in batches:
                 flight.append(self._launch(batch))
@@ -262,13 +265,17 @@ class SynthPipeline:
                     yield self._finish(flight.pop(0))
             while flight:
                 yield self._finish(flight.pop(0))
+            clean = True
         finally:
-            # the consumer stopped early (or a launch raised): the batches still in flight read tensors of one stream's pool on another -
-            # nothing may be released before their work has finished
-            for item in flight:
-                item[-1].synchronize()
-            if flight:
+            # the consumer stopped early, or a launch raised - possibly half way, with the acoustic model and part of the vocoder of a
+            # batch that never reached `flight` already queued: tensors of one stream's pool are being read on another, and nothing
+            # may go back to a pool before that work has finished.  Every stream of the pipeline is drained, unconditionally.
+            if not clean:
+                for item in flight:
+                    item[-1].synchronize()
                 self.s_ac.synchronize()
+                for st in self.s_vocs:
+                    st.synchronize()
 
 
 def synth_one_sample(targets, predictions, vocoder, model_config, preprocess_config):

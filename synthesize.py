@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import yaml
 
+import fastspeech2_amd
 from fastspeech2_amd.data import DevicePrefetcher, TextDataset
 from fastspeech2_amd.text import text_to_sequence
 from fastspeech2_amd.utils import SynthPipeline, get_model, get_vocoder
@@ -66,6 +67,9 @@ def parse_args(argv=None):
     parser.add_argument("--dtype", default=None, choices=[None, "fp32", "bf16"])
     parser.add_argument("--vocoder_dtype", default="fp32", choices=["fp32", "bf16"])
     parser.add_argument("--hifigan_dir", default="hifigan", help="directory with config.json + generator_*.pth.tar")
+    parser.add_argument("--hw_queues", type=int, default=fastspeech2_amd.HW_QUEUES_DEFAULT,
+                        help="HIP hardware queues of this process (GPU_MAX_HW_QUEUES; the runtime default 4 makes streams share queues: "
+                             "utils.SynthPipeline / the engine's side streams); the same for every world size; an exported value wins; 0 = leave the runtime default")
     parser.add_argument("--random_vocoder", action="store_true", help="allow a random-init vocoder when no checkpoint exists (smoke runs)")
     return parser.parse_args(argv)
 
@@ -97,4 +101,6 @@ def main(args):
 
 
 if __name__ == "__main__":
-    main(parse_args())
+    _args = parse_args()
+    fastspeech2_amd.configure_hw_queues(_args.hw_queues)      # before the first HIP call; the pipeline keeps 4+ streams busy
+    main(_args)

@@ -11,9 +11,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _clean_env(**extra):
+    """the driver's environment: no hardware-queue setting of the user's (bench.py decides, and says so in the line)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FASTSPEECH2_AMD_HW_QUEUES")}
+    env.update(extra)
+    return env
+
+
 def test_bench_line_contract(dev):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=_clean_env())
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().split("\n") if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -40,6 +47,7 @@ def test_bench_line_contract(dev):
     # window repeated and the median reported, the reference's own arithmetic (fp32) as a secondary figure of the same line
     cfg = d["config"]
     assert cfg["library"] == "fastspeech2_amd/libfs2hip.so" and cfg["dev_env"] == []
+    assert cfg["hw_queues"] == {"value": 16, "source": "fastspeech2_amd"} and 0.7 < cfg["valid_row_fraction"] <= 1.0
     assert cfg["windows"] >= 5 and len(cfg["window_ms_per_step"]) == cfg["windows"]
     assert sorted(cfg["window_ms_per_step"])[cfg["windows"] // 2] == d["ms_per_step"]
     assert cfg["fp32_ms_per_step"] > d["ms_per_step"] and 0.05 < cfg["fp32_frac_of_f32_peak"] < 1.0
@@ -56,6 +64,8 @@ def test_bench_line_contract(dev):
     sy = cfg["synth"]
     assert 0 < sy["rtf"] < 0.01 and sy["steps"] == 64 and "val.txt" in sy["workload"] and sy["mel_frames_per_s"] > 1e4
     assert abs(sy["rtf"] * sy["x_realtime"] - 1.0) < 0.02
+    # ... and in the reference's own arithmetic beside it (fp32 acoustic model + fp32 vocoder, same batches, same loop)
+    assert sy["fp32_rtf"] > sy["rtf"] and sy["fp32_ms_per_step"] > sy["ms_per_step"] and 0 < sy["fp32_frac_of_f32_peak"] < 1
     sr = sy["roofline"]
     assert sr["bound"] == "mfma" and 0 < sr["frac"] < 1 and abs(sr["frac"] - sr["achieved"] / sr["peak"]) < 1e-3
     sc = sy["cpu_baseline"]
@@ -84,7 +94,7 @@ def test_bench_two_ranks_shared_gpu(dev):
     """The N>1 launch the driver uses (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`), exercised with two
     ranks on this box's single GPU: gloo instead of RCCL (RCCL refuses two ranks on one device), everything else — gradient
     exchange hooks, global loss counts, barrier + max-over-ranks timing, rank 0's local roofline replay, joint exit — as shipped."""
-    env = dict(os.environ, FS2_BENCH_BACKEND="gloo", FS2_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = _clean_env(FS2_BENCH_BACKEND="gloo", FS2_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -102,6 +112,14 @@ def test_bench_two_ranks_shared_gpu(dev):
     assert "synth" not in d["config"]                                       # (replicas only; reported at N=1)
     ms = d["config"]["per_rank_local_ms"]
     assert len(ms) == 2 and min(ms) > 0 and abs(d["config"]["slowest_over_fastest"] - max(ms) / min(ms)) < 1e-2
+    # what the N = 8 line will be read for: the exchange's schedule, every rank's local step, and the part of the
+    # exchange backward did not hide = data-parallel step - slowest local step
+    ex = d["config"]["exchange"]
+    assert ex["collectives_total"] > 0 and ex["last_step_under_backward"] >= 1 and ex["last_step_in_finish"] <= 1
+    assert 100 < ex["flat_gradient_mb"] < 125
+    assert abs(d["config"]["exchange_exposed_ms"] - (d["ms_per_step"] - max(ms))) < 2e-3
+    # one hardware-queue setting for every world size, decided by bench.py (not by importing the package) and inherited by the ranks
+    assert d["config"]["hw_queues"] == {"value": 16, "source": "fastspeech2_amd"}
 
 
 def test_bench_two_ranks_libritts_buckets_differ(dev):

@@ -206,7 +206,7 @@ def test_bucket_schedule_at_the_real_parameter_layout():
     ends = [offsets[n] for n in names] + [total]
     assert ends == sorted(ends) and ends[0] > 0            # the PostNet + mel_linear block is final first
     flat = torch.zeros(total)
-    ex = GradExchange(flat, world_size=2)
+    ex = GradExchange(flat, world_size=2, collectives=True)      # schedule inspection only: _launch is replaced below
     launched = []
     ex._launch = lambda lo, hi, producers=(): launched.append((lo, hi, cur[0]))
     cur = [0]

@@ -17,6 +17,7 @@ import torch
 import yaml
 
 from evaluate import evaluate
+import fastspeech2_amd
 from fastspeech2_amd import ddp
 from fastspeech2_amd.data import BucketedBatchSampler, Dataset, DevicePrefetcher, train_batches
 from fastspeech2_amd.model import FastSpeech2Loss
@@ -150,12 +151,16 @@ def parse_args(argv=None):
     parser.add_argument("--dtype", default=None, choices=[None, "fp32", "bf16"],
                         help="compute dtype of the HIP engine (default: FS2_DTYPE or fp32; master weights are always fp32)")
     parser.add_argument("--hifigan_dir", default="hifigan")
+    parser.add_argument("--hw_queues", type=int, default=fastspeech2_amd.HW_QUEUES_DEFAULT,
+                        help="HIP hardware queues of this process (GPU_MAX_HW_QUEUES; the runtime default 4 makes streams share queues: "
+                             "utils.SynthPipeline / the engine's side streams); the same for every world size; an exported value wins; 0 = leave the runtime default")
     parser.add_argument("--no_vocoder", action="store_true", help="skip audio samples in the logs")
     return parser.parse_args(argv)
 
 
 if __name__ == "__main__":
     args = parse_args()
+    fastspeech2_amd.configure_hw_queues(args.hw_queues)       # before the first HIP call; identical for every world size
     configs = tuple(yaml.load(open(p, "r"), Loader=yaml.FullLoader)
                     for p in (args.preprocess_config, args.model_config, args.train_config))
     main(args, configs)
