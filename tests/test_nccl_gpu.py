@@ -42,6 +42,12 @@ def _one_rank_worker(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the hardware-queue setting train.py / bench.py make at EVERY world size, made here the same way (first thing, before this
+    # process's first HIP call): the RCCL communicator below lives next to the step's streams on 16 hardware queues
+    import fastspeech2_amd
+    for k in ("GPU_MAX_HW_QUEUES", "FASTSPEECH2_AMD_HW_QUEUES"):
+        os.environ.pop(k, None)
+    hwq = fastspeech2_amd.configure_hw_queues()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -77,7 +83,7 @@ def _one_rank_worker(port, q):
                 g1 = model.flat_gradients().clone()
             opt.step_and_update_lr(zero_grad=True)
         torch.cuda.synchronize()
-        q.put(dict(backend=dist.get_backend(), n_buckets=ex.n_buckets, per_step=per_step, n_elems=ex.n,
+        q.put(dict(hwq=hwq, backend=dist.get_backend(), n_buckets=ex.n_buckets, per_step=per_step, n_elems=ex.n,
                    calls=[c[0] for c in calls], on_comm=[c[1] == ex.comm_stream.cuda_stream for c in calls if c[0] > 2],
                    main_is_comm=main.cuda_stream == ex.comm_stream.cuda_stream,
                    g=g1.cpu().numpy(), par=model.flat_parameters().detach().cpu().numpy()))
@@ -103,6 +109,7 @@ def test_one_rank_step_through_rccl_matches_plain_step(dev):
     r = q.get(timeout=600)
     p.join(120)
     assert p.exitcode == 0 and r["backend"] == "nccl"
+    assert r["hwq"] == {"value": 16, "source": "fastspeech2_amd"}   # RCCL next to the step on the hardware-queue setting every rank count gets
     per_bucket = (1 << 20) // 4
     expect = -(-r["n_elems"] // per_bucket)                       # tail pieces are a quarter bucket: at least this many
     assert r["n_buckets"] >= 2 * expect, (r["n_buckets"], expect)

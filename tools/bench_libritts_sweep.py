@@ -28,9 +28,10 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--groups", default="4,16,64")
-    ap.add_argument("--nsteps", type=int, default=8)
+    ap.add_argument("--nsteps", type=int, default=0, help="0 = EVERY step of the epoch (the same utterances for every window size: "
+                    "frames/s are comparable); n > 0 = n steps spread evenly over the epoch")
     ap.add_argument("--world", type=int, default=1)
-    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=48)
     a = ap.parse_args()
     fastspeech2_amd.configure_hw_queues()
@@ -55,7 +56,7 @@ def main():
         # mel rows: T = sum of per-phoneme durations (4..10), capped by max_seq_len = 1000 - from the real batches below for the sample,
         # from the phoneme counts for the epoch (the same ratio up to the cap)
         mel_valid_epoch = sum(int(l.sum()) for l in lens) / sum(min(int(l.max()) * frames_per_phoneme, 1000.0) / frames_per_phoneme * len(l) for l in lens)
-        pick = [(2 * i + 1) * len(steps) // (2 * a.nsteps) for i in range(a.nsteps)]
+        pick = [(2 * i + 1) * len(steps) // (2 * a.nsteps) for i in range(a.nsteps)] if a.nsteps > 0 else list(range(len(steps)))
         tot_valid = tot_padded = 0.0
         tot_t = 0.0
         per = []
@@ -64,7 +65,7 @@ def main():
             b = {k: (lens_to_device(v, device) if k in ("src_lens", "mel_lens") else v.to(device) if isinstance(v, torch.Tensor) else v)
                  for k, v in b.items()}
             step, _ = bench.make_step(model, loss_fn, opt, b, None)
-            for _ in range(3):
+            for _ in range(2 if a.nsteps == 0 else 3):
                 step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -82,7 +83,7 @@ def main():
                "ms_per_step_mean": round(tot_t / len(pick) * 1e3, 3),
                "step_frac_of_peak_valid_rows": round(tot_valid / tot_t * bench.train_flop_per_frame(args) / 2.5e15, 4),
                "step_frac_of_peak_padded_rows": round(tot_padded / tot_t * bench.train_flop_per_frame(args) / 2.5e15, 4),
-               "steps": per}
+               "steps": per if a.nsteps > 0 else per[::17]}
         out.append(rec)
         print(json.dumps(rec), flush=True)
     return out
