@@ -232,7 +232,8 @@ extern "C" int fs2_ln_fwd(void* y, const void* res, const float* gamma, const fl
 //   d2 = dz * dropmask_pre * (relu_bwd ? z > 0 : 1)   -> gradient of the GEMM output y
 //   dgamma += sum_rows g*xhat ; dbeta += sum_rows g
 struct LnBwdArgs {
-    const void* z; const void* dout; const float* gamma; const int32_t* lens;
+    const void* z; const void* dout; const void* dout2;   // upstream gradient = dout (+ dout2 when non-null)
+    const float* gamma; const int32_t* lens;
     const float* mean; const float* rstd;
     const void* d1_add;    // optional tensor added into d1 (fuses the "+ upstream residual gradient")
     void* d1; void* d2;    // either may be null
@@ -268,6 +269,10 @@ __global__ void __launch_bounds__(512) ln_bwd_kernel(LnBwdArgs a) {
             if (c < a.C) {
                 float4 zz = ld4<T>(z + c);
                 float4 g = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4<T>(dout + c);
+                if (a.dout2 && !pad) {
+                    const float4 g2 = ld4<T>(reinterpret_cast<const T*>(a.dout2) + (size_t)row * a.C + c);
+                    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+                }
                 if (a.p_post > 0.f) {
                     uint32_t e = (uint32_t)row * (uint32_t)a.C + c;
                     g.x *= fs2_drop_scale(a.seed_post, e, a.p_post, ik_post);
@@ -358,11 +363,12 @@ __global__ void __launch_bounds__(512) ln_bwd_kernel(LnBwdArgs a) {
 // (z, dout, d1_add, mean, rstd, lens) are issued before the current pair is reduced and stored, so every wave keeps a full
 // set of loads in flight across its whole row loop.  The host sizes the grid so that all waves run the same number of
 // iterations (44400 rows: 925 workgroups x 3 instead of 1024 x 2.7).
-struct LnBwdRow { uint4 z, g, r; float mean, rstd; int len; };
+struct LnBwdRow { uint4 z, g, g2, r; float mean, rstd; int len; };
 __device__ __forceinline__ void ln_bwd_c256_load(const LnBwdArgs& a, int row, int c, LnBwdRow& q) {
     const int rc = min(row, a.rows - 1);
     q.z = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.z) + (size_t)rc * 256 + c);
     q.g = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.dout) + (size_t)rc * 256 + c);
+    if (a.dout2) q.g2 = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.dout2) + (size_t)rc * 256 + c);
     if (a.d1 && a.d1_add) q.r = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.d1_add) + (size_t)rc * 256 + c);
     q.mean = a.mean[rc]; q.rstd = a.rstd[rc];
     q.len = a.lens ? a.lens[rc / a.S] : a.S;
@@ -384,6 +390,7 @@ __global__ void __launch_bounds__(512) ln_bwd_c256_bf16_kernel(LnBwdArgs a) {
     int row = (blockIdx.x * 8 + w) * 2 + hh;
     LnBwdRow nx;
     nx.r = make_uint4(0, 0, 0, 0);
+    nx.g2 = make_uint4(0, 0, 0, 0);
     ln_bwd_c256_load(a, row, c, nx);
     for (; row - hh < a.rows; row += stride) {
         const LnBwdRow q = nx;
@@ -394,6 +401,12 @@ __global__ void __launch_bounds__(512) ln_bwd_c256_bf16_kernel(LnBwdArgs a) {
         float z[8], g[8], x[8];
         unpack8(q.z, z);
         unpack8(q.g, g);
+        if (a.dout2) {                                   // (kernel-uniform)
+            float g2[8];
+            unpack8(q.g2, g2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += g2[j];
+        }
         if (a.p_post > 0.f) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] *= fs2_drop_scale(a.seed_post, e + j, a.p_post, ik_post);
@@ -486,17 +499,29 @@ __global__ void __launch_bounds__(256) ln_bwd_reduce_kernel(const float* __restr
     atomicAdd(c < C ? dgamma + c : dbeta + (c - C), t);
 }
 
+extern "C" int fs2_ln_bwd_sum(const void* z, const void* dout, const void* dout2, const float* gamma, const int32_t* lens, const float* mean,
+                              const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
+                              float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
+                              const uint64_t* seed_dev, int relu_bwd, int dtype, hipStream_t stream);
 extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_t* lens, const float* mean,
                           const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
                           float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
                           const uint64_t* seed_dev, int relu_bwd, int dtype, hipStream_t stream) {
+    return fs2_ln_bwd_sum(z, dout, nullptr, gamma, lens, mean, rstd, d1_add, d1, d2, dgamma, dbeta, partial_ws, B, S, C, p_pre, seed_pre,
+                          p_post, seed_post, seed_dev, relu_bwd, dtype, stream);
+}
+
+extern "C" int fs2_ln_bwd_sum(const void* z, const void* dout, const void* dout2, const float* gamma, const int32_t* lens, const float* mean,
+                              const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
+                              float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
+                              const uint64_t* seed_dev, int relu_bwd, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(z && dout && gamma && mean && rstd && ((dgamma != nullptr) == (dbeta != nullptr)), "ln_bwd: null pointer");
     const bool reduce_now = dgamma != nullptr;              // both null: the caller runs fs2_ln_bwd_reduce later (any stream)
     FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * FS2_LN_MAXV, "ln_bwd: unsupported C=%d", C);
     // the wave-uniform early break in the reduction requires whole 256-channel groups
     FS2_CHECK_ARG(C % 256 == 0, "ln_bwd: C=%d must be a multiple of 256", C);
     LnBwdArgs a;
-    a.z = z; a.dout = dout; a.gamma = gamma; a.lens = lens; a.mean = mean; a.rstd = rstd; a.d1_add = d1_add; a.d1 = d1; a.d2 = d2;
+    a.z = z; a.dout = dout; a.dout2 = dout2; a.gamma = gamma; a.lens = lens; a.mean = mean; a.rstd = rstd; a.d1_add = d1_add; a.d1 = d1; a.d2 = d2;
     a.dgamma = dgamma; a.dbeta = dbeta; a.rows = B * S; a.S = S; a.C = C; a.p_pre = p_pre; a.p_post = p_post;
     a.seed_pre = seed_pre; a.seed_post = seed_post; a.seed_dev = seed_dev; a.relu_bwd = relu_bwd;
     FS2_CHECK_ARG(partial_ws, "ln_bwd: partial_ws (FS2_LN_BWD_GRID*2*C floats) is required");
@@ -509,7 +534,7 @@ extern "C" int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, c
     }
     int grid = fs2_cdiv(a.rows, 8);
     if (grid > FS2_LN_BWD_GRID) grid = FS2_LN_BWD_GRID;
-    const bool al16 = ((((uintptr_t)z | (uintptr_t)dout | (uintptr_t)d1_add | (uintptr_t)d1 | (uintptr_t)d2) & 15) == 0);
+    const bool al16 = ((((uintptr_t)z | (uintptr_t)dout | (uintptr_t)dout2 | (uintptr_t)d1_add | (uintptr_t)d1 | (uintptr_t)d2) & 15) == 0);
     static const int ln_fast = fs2_dev_env("FS2_LN_FAST", 3);
     if ((ln_fast & 2) && dtype == FS2_BF16 && C == 256 && al16) {
         const int iters = fs2_cdiv(a.rows, 16 * FS2_LN_BWD_GRID);        // same trip count for every wave

@@ -10,6 +10,7 @@ struct WgradArgs {
     float* dbias;          // optional: dbias[n] += sum_m dY[m][n], fused into the blocks that own (c-tile 0, tap group 0)
     const int32_t* lens;   // optional: dY rows t >= lens[seq] are known to be zero -> their K-tiles are skipped
     int M, N, Cin, S, taps, dil, pad, rows_per_split, g3, dbg;
+    int n_tiles, n_splits, per_xcd;   // fs2_wgrad.hip's 1-D grid (XCD-aware placement of (split, tile) pairs; see conv_wgrad_tg_kernel)
     float* slab;           // optional split-K scratch: split s stores its partial tile (plain stores) at slab + s * slab_stride in the
     long slab_stride;      // layout of dW, its bias partials behind it (slab_stride = N*taps*Cin + N floats); wgrad_finalize_kernel
                            // sums the splits into dW / dbias.  null: fp32 atomics straight into dW (round-1/2 path)

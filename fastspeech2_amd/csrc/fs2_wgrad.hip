@@ -66,7 +66,7 @@ __device__ __forceinline__ int tg_sload(const int32_t* p) {
 }
 
 template <int NT>
-__device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char* smem, int tile_n, int tile_c, int tap0) {
+__device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char* smem, int tile_n, int tile_c, int tap0, int split) {
     static_assert(NT >= 1 && NT <= 5, "tap group of 1 .. 5 taps");
     constexpr int NR = (8 + NT - 1 + 3) / 4;             // transposing reads per X run (4 rows each): 2 (NT = 1) or 3
     constexpr int TG_X_ROWS = TgCfg<NT>::X_ROWS, TG_BUF_BYTES = TgCfg<NT>::BUF_BYTES, NBUF = TgCfg<NT>::NBUF, D = NBUF - 1;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
     const int shift0 = tap0 - a.pad;                     // tile row r of the X image = sequence row t0 + shift0 + r (dil == 1)
     const int tps = (a.S + 63) >> 6;                     // K-tiles per sequence
     const int nunits = (a.M / a.S) * tps;
-    const int ubeg = blockIdx.y * a.rows_per_split;      // units per split
+    const int ubeg = split * a.rows_per_split;           // units per split
     const int uend = min(nunits, ubeg + a.rows_per_split);
     const unsigned smem_u = lds_addr(smem);
 
@@ -277,7 +277,7 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
 
     // ---- epilogue: acc[t][mb][r]: row n = wm*64 + mb*32 + (r&3) + 8*(r>>2) + 4*fh, column c = wn*32 + fl
     const int fl = lane & 31, fh = lane >> 5;
-    float* const outW = a.slab ? a.slab + (size_t)blockIdx.y * a.slab_stride : a.dW;
+    float* const outW = a.slab ? a.slab + (size_t)split * a.slab_stride : a.dW;
     if (do_bias) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -309,17 +309,29 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
     }
 }
 
-// grid.x = (n-tile, c-tile, tap group): the first a.g3 groups take NF taps each, one more group (if NR) the remaining NR taps;
-// grid.y = K-splits.  One 512-thread workgroup per CU (102 KiB of LDS, <= 256 registers per wave: two waves per SIMD).
+// A (K-split, tile) pair per workgroup; tile = (n-tile, c-tile, tap group): the first a.g3 groups take NF taps each, one more group
+// (if NR) the remaining NR taps.  One 512-thread workgroup per CU (102 KiB of LDS, <= 256 registers per wave: two waves per SIMD).
+// XCD-AWARE PLACEMENT (round 6).  The tiles of ONE split read the same rows of dY and X - each dY column block ntc x groups times,
+// each X column block ntn x groups times.  Rounds 3-5 launched a (tiles, splits) grid: the dispatcher deals consecutive
+// workgroups round-robin to the 8 XCDs, so the tiles of a split landed on 8 different L2s and every one of them fetched its
+// operands from the Infinity Cache / HBM again (PMC r05zzz: one-tap launches 104 MB fetched for 30-45 MB of operands, 5 + 4 taps
+// 229 MB for 114 MB).  Now the grid is 1-D and padded to 8 x per_xcd: workgroup `lin` sits on XCD lin & 7 (the dispatcher's
+// rule) and takes pair p = (lin & 7) * per_xcd + (lin >> 3) of the split-major pair list - every XCD gets the same number of
+// pairs, a CONTIGUOUS range of them (the tiles of one split, or of two neighbouring splits), and they start together, so the
+// second reader of a row block hits in its XCD's L2.
 template <int NF, int NR>
 __global__ void __launch_bounds__(512, 2) conv_wgrad_tg_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF x [dY 64 rows | X 64 / 72 rows][256 B]
     const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 127) >> 7;
-    int bx = blockIdx.x;
+    const int kx = blockIdx.x >> 3;
+    const int pair = (int)(blockIdx.x & 7) * a.per_xcd + kx;
+    if (pair >= a.n_tiles * a.n_splits) return;              // padding of the last XCD's range (no barrier has been executed)
+    const int split = pair / a.n_tiles;
+    int bx = pair - split * a.n_tiles;
     const int tile_n = bx % ntn; bx /= ntn;
     const int tile_c = bx % ntc; bx /= ntc;
-    if (NR == 0 || bx < a.g3) wgrad_tg_body<NF>(a, smem, tile_n, tile_c, bx * NF);
-    else wgrad_tg_body<(NR ? NR : 1)>(a, smem, tile_n, tile_c, a.g3 * NF);
+    if (NR == 0 || bx < a.g3) wgrad_tg_body<NF>(a, smem, tile_n, tile_c, bx * NF, split);
+    else wgrad_tg_body<(NR ? NR : 1)>(a, smem, tile_n, tile_c, a.g3 * NF, split);
 }
 
 template <int NF, int NR>
@@ -330,7 +342,9 @@ static void launch_tg(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
     once.run([&] { (void)hipFuncSetAttribute((const void*)conv_wgrad_tg_kernel<NF, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
     a.g3 = p.g_first;
     a.rows_per_split = p.ups;
-    conv_wgrad_tg_kernel<NF, NR><<<dim3((unsigned)p.tiles, (unsigned)p.splits), 512, dyn, stream>>>(a);
+    a.n_tiles = p.tiles; a.n_splits = p.splits;
+    a.per_xcd = (p.tiles * p.splits + 7) / 8;
+    conv_wgrad_tg_kernel<NF, NR><<<dim3((unsigned)(8 * a.per_xcd)), 512, dyn, stream>>>(a);
 }
 
 bool fs2_wgrad_tg_launch(WgradArgs a, const WgradPlan& p, hipStream_t stream) {

@@ -85,6 +85,7 @@ class Engine:
         # the device tensors (`_fs2_host`, lost by .to() / clone / slicing, stale when a static buffer is refilled with copy_)
         self.length_hint = None
         self._wgrad_ws = ops.WgradWorkspaces()      # split-K scratch of the weight gradients: lives and dies with this engine
+        self.res_in_ln = True           # see _fft_bwd: residual-branch gradients are added by the LayerNorm backward below, not by the dgrad epilogue
         self.fuse_proj_ln = False       # see _proj_ln: True = every N = 256 projection, "stream" = only where the streaming kernel runs it
         self._pack_pending = False
         self._bn_ws = {}
@@ -482,13 +483,20 @@ class Engine:
             sv.p, sv.site = p, site
         return out, sv
 
-    def _fft_bwd(self, W, G, pre, sv, dout, lens, B, S, n_head, seed_dev):
+    def _fft_bwd(self, W, G, pre, sv, dout, lens, B, S, n_head, seed_dev, dout2=None, split_out=False):
+        """backward of one FFT block.  The gradient of a sub-layer's input is "data gradient through the sub-layer + the gradient
+        that bypassed it" (output + residual, transformer/SubLayers.py:55,91).  `res_in_ln` (default): the two terms travel as a
+        PAIR to the LayerNorm backward below, which adds them while it reads its rows (ops.ln_bwd dout2) - the contraction that
+        makes the first term then has no residual operand (its epilogue paid 25-45 us per launch for 16 dependent loads behind
+        the tile's stores).  dout2: second term of this block's upstream gradient; split_out: return (dx, bypass) instead of their
+        sum (the caller hands the pair to the next block)."""
         ks = self.tc["conv_kernel_size"]
         a, f = pre + "slf_attn.", pre + "pos_ffn."
         p = sv.p
+        pair = self.res_in_ln
         dz2, dy2 = self._ln_bwd(sv.z2, dout, self.P[f + "layer_norm.weight"], lens, sv.mean2, sv.rstd2,
                               G[f + "layer_norm.weight"], G[f + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
-                              p_pre=p, **_seed_kw("seed_pre", sv.site + 1, seed_dev))
+                              p_pre=p, dout2=dout2, **_seed_kw("seed_pre", sv.site + 1, seed_dev))
         if dy2 is None:
             dy2 = dz2
         # all gradients below are zero on padded rows (ln_bwd zeroes them) -> lens lets every kernel skip those tiles
@@ -496,17 +504,20 @@ class Engine:
         self._wgrad(G[f + "w_2.weight"], G[f + "w_2.bias"], dy2, sv.hid, S, taps=ks[1], pad=(ks[1] - 1) // 2, lens=lens)
         dhid = self._dgemm(W, f + "w_2", dy2, S, taps=ks[1], pad=(ks[1] - 1) // 2, act=ACT_GATE, res=sv.hid, lens=l2)
         self._wgrad(G[f + "w_1.weight"], G[f + "w_1.bias"], dhid, sv.h, S, taps=ks[0], pad=(ks[0] - 1) // 2, lens=l2)
-        dh = self._dgemm(W, f + "w_1", dhid, S, taps=ks[0], pad=(ks[0] - 1) // 2, res=dz2, lens=lens)
+        dh = self._dgemm(W, f + "w_1", dhid, S, taps=ks[0], pad=(ks[0] - 1) // 2, res=None if pair else dz2, lens=lens)
         dz1, dy1 = self._ln_bwd(sv.z1, dh, self.P[a + "layer_norm.weight"], lens, sv.mean1, sv.rstd1,
                               G[a + "layer_norm.weight"], G[a + "layer_norm.bias"], B, S, want_d1=True, want_d2=p > 0,
-                              p_pre=p, **_seed_kw("seed_pre", sv.site, seed_dev))
+                              p_pre=p, dout2=dz2 if pair else None, **_seed_kw("seed_pre", sv.site, seed_dev))
         if dy1 is None:
             dy1 = dz1
         self._wgrad(G[a + "fc.weight"], G[a + "fc.bias"], dy1, sv.ctx, S, lens=lens)
         dctx = self._dgemm(W, a + "fc", dy1, S, lens=lens)
         dqkv = ops.attn_bwd(sv.qkv, sv.ctx, dctx, sv.lse, lens, B, S, n_head, self.d // n_head)
         self._wgrad(G[a + "qkv.weight"], G[a + "qkv.bias"], dqkv, sv.x, S, lens=lens)
-        return self._dgemm(W, a + "qkv", dqkv, S, res=dz1)
+        if split_out and pair:
+            return self._dgemm(W, a + "qkv", dqkv, S), dz1
+        dx = self._dgemm(W, a + "qkv", dqkv, S, res=dz1)
+        return (dx, None) if split_out else dx
 
     def _pred_fwd(self, W, kind, x, lens, B, S, p, seed_dev, site, keep):
         pre = f"variance_adaptor.{kind}_predictor."
@@ -803,9 +814,12 @@ class Engine:
         # ---- decoder
         n_head = self.tc["decoder_head"]
         va_first = "variance_adaptor.energy_predictor.linear_layer.weight"
+        dy2 = None
         for i in reversed(range(self.tc["decoder_layer"])):
             self._ready(f"decoder.layer_stack.{i}.pos_ffn.layer_norm.weight")
-            dy = self._fft_bwd(W, G, f"decoder.layer_stack.{i}.", sv.dec[i], dy, sv.dec_lens32, B, T, n_head, seed_dev)
+            r = self._fft_bwd(W, G, f"decoder.layer_stack.{i}.", sv.dec[i], dy, sv.dec_lens32, B, T, n_head, seed_dev, dout2=dy2,
+                              split_out=i > 0)            # (the first block's input gradient leaves the stack: one tensor)
+            dy, dy2 = r if i > 0 else (r, None)
         self._ready(va_first)
         # ---- frame-level variance branches + length regulator
         dpp = dp.contiguous() if dp is not None else None
@@ -844,9 +858,12 @@ class Engine:
             ops.rowvec_bwd(dx, G["speaker_emb.weight"], sv.speakers, B, L)
         # ---- encoder
         n_head = self.tc["encoder_head"]
+        dx2 = None
         for i in reversed(range(self.tc["encoder_layer"])):
             self._ready(f"encoder.layer_stack.{i}.pos_ffn.layer_norm.weight")
-            dx = self._fft_bwd(W, G, f"encoder.layer_stack.{i}.", sv.enc[i], dx, sv.src_lens32, B, L, n_head, seed_dev)
+            r = self._fft_bwd(W, G, f"encoder.layer_stack.{i}.", sv.enc[i], dx, sv.src_lens32, B, L, n_head, seed_dev, dout2=dx2,
+                              split_out=i > 0)
+            dx, dx2 = r if i > 0 else (r, None)
         self._ready("encoder.src_word_emb.weight")
         ops.embed_bwd(sv.texts, dx, G["encoder.src_word_emb.weight"], pad_idx=0)
         self._side_join()

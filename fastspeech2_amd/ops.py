@@ -318,14 +318,16 @@ def gemm_res_ln(x, wpacked, bias, res, gamma, beta, lens, tmap, B, S, eps=1e-5, 
 
 
 def ln_bwd(z, dout, gamma, lens, mean, rstd, dgamma, dbeta, B, S, want_d1=True, want_d2=False, d1_add=None, p_pre=0.0,
-           seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False, seed_dev=None, defer=False):
+           seed_pre=0, p_post=0.0, seed_post=0, relu_bwd=False, seed_dev=None, defer=False, dout2=None):
     """defer=True: the affine-gradient reduction is NOT launched; returns (d1, d2, ws) and the caller runs
-    ln_bwd_reduce(ws, C, dgamma, dbeta) later (any stream ordered after this call; ws must stay alive until then)."""
+    ln_bwd_reduce(ws, C, dgamma, dbeta) later (any stream ordered after this call; ws must stay alive until then).
+    dout2: the upstream gradient is dout + dout2 (fs2_ln_bwd_sum: the term that bypassed the sub-layer above, added here instead
+    of in the epilogue of the contraction that made dout)."""
     C = z.shape[-1]
     d1 = torch.empty_like(z) if want_d1 else None
     d2 = torch.empty_like(z) if want_d2 else None
     ws = torch.empty(1024 * 2 * C + 4, device=z.device, dtype=torch.float32)
-    _lib.call("fs2_ln_bwd", _p(z), _p(dout), _p(gamma), _p(lens), _p(mean), _p(rstd), _p(d1_add), _p(d1), _p(d2),
+    _lib.call("fs2_ln_bwd_sum", _p(z), _p(dout), _p(dout2), _p(gamma), _p(lens), _p(mean), _p(rstd), _p(d1_add), _p(d1), _p(d2),
               _p(None if defer else dgamma), _p(None if defer else dbeta), _p(ws), B, S, C, p_pre, seed_pre, p_post, seed_post,
               _p(seed_dev), int(relu_bwd), dt(z), _stream())
     if defer:

@@ -96,10 +96,13 @@ def make_configs(dec_layers=4, multi_speaker=False, frame_level=False, dropout=T
 
 
 def synthetic_batch(seed, B, L, dur_lo=2, dur_hi=8, n_mel=80, n_vocab=361, n_speaker=1, min_len_frac=0.6,
-                    max_seq_len=1000, frame_level=False, src_lens=None, sort=True):
+                    max_seq_len=1000, frame_level=False, src_lens=None, sort=True, utt_durations=None):
     """LJSpeech-shaped synthetic batch: the reference's 12-tuple minus ids/raw_texts.
     Returns dict of CPU tensors + python ints.  src_lens (optional): the utterances' phoneme counts (then B = len(src_lens),
-    L = their maximum; `sort` = False keeps their order, as a TextDataset batch does)."""
+    L = their maximum; `sort` = False keeps their order, as a TextDataset batch does).  utt_durations (optional, with src_lens):
+    one 1-D integer tensor of per-phoneme durations PER UTTERANCE - an utterance then has the same frames whatever batch it is
+    dealt into (a corpus: tools/bench_libritts_sweep.py); without it the durations are drawn per batch and the whole batch is
+    shrunk until its longest utterance fits max_seq_len."""
     g = torch.Generator().manual_seed(seed)
     if src_lens is not None:
         src_lens = torch.as_tensor(src_lens, dtype=torch.int64).clone()
@@ -112,6 +115,12 @@ def synthetic_batch(seed, B, L, dur_lo=2, dur_hi=8, n_mel=80, n_vocab=361, n_spe
         src_lens, _ = torch.sort(src_lens, descending=True)
     texts = torch.randint(1, n_vocab, (B, L), generator=g)
     durations = torch.randint(dur_lo, dur_hi + 1, (B, L), generator=g)
+    if utt_durations is not None:
+        assert not sort and len(utt_durations) == B
+        durations = torch.zeros(B, L, dtype=torch.int64)
+        for i, d in enumerate(utt_durations):
+            assert d.numel() == int(src_lens[i]) and int(d.sum()) <= max_seq_len
+            durations[i, :d.numel()] = d
     valid = torch.arange(L).unsqueeze(0) < src_lens.unsqueeze(1)
     texts = texts * valid
     durations = durations * valid

@@ -169,6 +169,15 @@ int fs2_ln_bwd(const void* z, const void* dout, const float* gamma, const int32_
                float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, const uint64_t* seed_dev,
                int relu_bwd, int dtype, fs2_stream_t stream);
 int fs2_ln_bwd_reduce(const float* partial_ws, int C, float* dgamma /*+=*/, float* dbeta /*+=*/, fs2_stream_t stream);
+/* fs2_ln_bwd with the upstream gradient given as a SUM of two tensors, dout + dout2 (dout2 may be NULL = fs2_ln_bwd): the residual
+ * branch's gradient reaches the LayerNorm below a sub-layer as "data gradient of the sub-layer + gradient that bypassed it"
+ * (autograd of `output + residual`, transformer/SubLayers.py:55,91).  Rounds 1-5 added the bypass term in the epilogue of the
+ * contraction that produced the first (16 dependent residual loads behind the tile's own stores: 25-45 us per launch); here it is one
+ * more coalesced row read of an HBM-bound kernel. */
+int fs2_ln_bwd_sum(const void* z, const void* dout, const void* dout2, const float* gamma, const int32_t* lens, const float* mean,
+                   const float* rstd, const void* d1_add, void* d1, void* d2, float* dgamma, float* dbeta,
+                   float* partial_ws, int B, int S, int C, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, const uint64_t* seed_dev,
+                   int relu_bwd, int dtype, fs2_stream_t stream);
 
 /* ---- BatchNorm1d (+tanh, +dropout) of PostNet: transformer/Layers.py:129-137 ------------------------ */
 /* Column sums are bit-reproducible: every reducing launch stores per-workgroup partial sums in a workspace and a second tiny

@@ -562,6 +562,21 @@ def test_layernorm_production_shape_bf16(dev, form):
         assert_rounding_only(d2, dz * (zr > 0), torch.bfloat16, (form, "d2 relu"))
     for got, ref, nm in ((dg, (gdo * xh).sum(0), "dgamma"), (db, gdo.sum(0), "dbeta")):
         assert ((got.double() - ref).norm() / ref.norm()).item() < 1e-5, (form, nm)
+    # the upstream gradient as a PAIR (fs2_ln_bwd_sum: dout + dout2 added while the rows are read - round 6: the FFT blocks'
+    # residual-branch gradient no longer goes through a contraction epilogue): every output against fp64 of the summed gradient
+    dout2 = torch.randn(M, C, generator=g).to(dev).to(torch.bfloat16)
+    gdo2 = (dout.double() + dout2.double()) * valid
+    gg2 = gdo2 * gamma.double()
+    dzs = rstd * (gg2 - gg2.mean(1, keepdim=True) - xh * (gg2 * xh).mean(1, keepdim=True))
+    dg2 = torch.zeros(C, device=dev); db2 = torch.zeros(C, device=dev)
+    e1, e2 = ops.ln_bwd(y, dout, gamma, lens, mean, rs, dg2, db2, B, S, want_d1=resid, want_d2=True, d1_add=d1a, relu_bwd=not resid, dout2=dout2)
+    if resid:
+        assert_rounding_only(e1, dzs + d1a.double(), torch.bfloat16, (form, "d1, pair"))
+        assert_rounding_only(e2, dzs, torch.bfloat16, (form, "d2, pair"))
+    else:
+        assert_rounding_only(e2, dzs * (zr > 0), torch.bfloat16, (form, "d2 relu, pair"))
+    for got, ref, nm in ((dg2, (gdo2 * xh).sum(0), "dgamma"), (db2, gdo2.sum(0), "dbeta")):
+        assert ((got.double() - ref).norm() / ref.norm()).item() < 1e-5, (form, nm, "pair")
     # dropout forms: the backward regenerates the forward's masks (d2 is zero exactly where the pre-LN dropout dropped y)
     y2 = (torch.randn(M, C, generator=g) + 2.0).to(dev).to(torch.bfloat16)          # away from 0: a zero in z - res marks a dropped element
     y2[y2 == 0] = 1.0                                                                # (11 M samples: one does land on 0)

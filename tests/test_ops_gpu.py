@@ -211,6 +211,19 @@ def test_layernorm(dev, dtype, tol):
     assert rel_err(d1.float(), yr.grad) < tol * 2
     assert rel_err(dg, gr.grad) < tol * 2
     assert rel_err(db, br.grad) < tol * 2
+    # the upstream gradient as a pair dout + dout2 (fs2_ln_bwd_sum): fp32 adds the same two numbers the caller would have added -
+    # bit-identical to the summed call; bf16 adds the two STORED values in fp32 (no rounding of the sum)
+    half = (0.5 * dout).to(dev).to(dtype)
+    dg2 = torch.zeros(C, device=dev); db2 = torch.zeros(C, device=dev)
+    p1, _ = ops.ln_bwd(yd, half, gamma.to(dev), lens.to(dev), mean, rstd, dg2, db2, B, S, dout2=half)
+    if dtype == torch.float32:
+        dg1 = torch.zeros(C, device=dev); db1 = torch.zeros(C, device=dev)
+        s1, _ = ops.ln_bwd(yd, half + half, gamma.to(dev), lens.to(dev), mean, rstd, dg1, db1, B, S)
+        assert torch.equal(p1, s1)
+    zz = z.detach().clone().requires_grad_(True)
+    ref2 = F.layer_norm(zz, (C,), gr.detach(), br.detach(), 1e-5).masked_fill(pad.unsqueeze(1), 0)
+    ref2.backward(2 * half.float().cpu().double())
+    assert rel_err(p1.float(), zz.grad) < tol * 2
 
 
 def test_layernorm_dropout_consistency(dev):

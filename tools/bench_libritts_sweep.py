@@ -48,6 +48,16 @@ def main():
     g = torch.Generator().manual_seed(99)
     pool = torch.clamp(torch.exp(torch.randn(8192, generator=g) * 0.78 + 3.89), 5, 250).long()     # bench.build's pool
     frames_per_phoneme = 7.0                                                                        # dur_lo = 4 .. dur_hi = 10
+    # a CORPUS: every utterance has its own per-phoneme durations (4 .. 10 frames, seeded by its index), shrunk on its own until it
+    # fits max_seq_len = 1000 frames - so the epoch's valid frames are the same for every window size (the per-batch generator
+    # shrinks a whole batch when its longest utterance overflows, which made the totals depend on how the utterances were dealt)
+    utt_dur = []
+    for i in range(len(pool)):
+        d = torch.randint(4, 11, (int(pool[i]),), generator=torch.Generator().manual_seed(50000 + i))
+        while int(d.sum()) > 1000:
+            d = torch.clamp(d - 1, min=1)
+        utt_dur.append(d)
+    utt_frames = torch.tensor([int(d.sum()) for d in utt_dur])
     out = []
     for G in [int(x) for x in a.groups.split(",")]:
         steps = list(iter(BucketedBatchSampler(pool.numpy(), a.batch, world_size=a.world, rank=0, group_size=G, shuffle=True, seed=1234)))
@@ -55,13 +65,15 @@ def main():
         src_valid = sum(int(l.sum()) for l in lens) / sum(int(l.max()) * len(l) for l in lens)
         # mel rows: T = sum of per-phoneme durations (4..10), capped by max_seq_len = 1000 - from the real batches below for the sample,
         # from the phoneme counts for the epoch (the same ratio up to the cap)
-        mel_valid_epoch = sum(int(l.sum()) for l in lens) / sum(min(int(l.max()) * frames_per_phoneme, 1000.0) / frames_per_phoneme * len(l) for l in lens)
+        mel_valid_epoch = sum(int(utt_frames[s].sum()) for s in steps) / sum(int(utt_frames[s].max()) * len(s) for s in steps)
         pick = [(2 * i + 1) * len(steps) // (2 * a.nsteps) for i in range(a.nsteps)] if a.nsteps > 0 else list(range(len(steps)))
         tot_valid = tot_padded = 0.0
         tot_t = 0.0
         per = []
         for si in pick:
-            b = synthetic_batch(1234 + si, 0, 0, dur_lo=4, dur_hi=10, n_speaker=2456, src_lens=pool[steps[si]].tolist())
+            order = sorted(steps[si], key=lambda i: -int(pool[i]))                                 # the collate function sorts by text length
+            b = synthetic_batch(1234 + si, 0, 0, n_speaker=2456, src_lens=pool[order].tolist(), sort=False,
+                                utt_durations=[utt_dur[i] for i in order])
             b = {k: (lens_to_device(v, device) if k in ("src_lens", "mel_lens") else v.to(device) if isinstance(v, torch.Tensor) else v)
                  for k, v in b.items()}
             step, _ = bench.make_step(model, loss_fn, opt, b, None)
@@ -77,7 +89,7 @@ def main():
             tot_valid += valid; tot_padded += padded; tot_t += dt
             per.append({"step": si, "L": int(b["max_src_len"]), "T": int(b["max_mel_len"]), "valid": round(valid / padded, 3), "ms": round(dt * 1e3, 3)})
         rec = {"group_size": G, "world": a.world, "window_items": G * a.world * a.batch, "epoch_steps": len(steps),
-               "epoch_valid_phoneme_rows": round(src_valid, 4), "epoch_valid_mel_rows_est": round(min(mel_valid_epoch, 1.0), 4),
+               "epoch_valid_phoneme_rows": round(src_valid, 4), "epoch_valid_mel_rows": round(mel_valid_epoch, 4),
                "sample_valid_mel_rows": round(tot_valid / tot_padded, 4),
                "valid_frames_per_s": round(tot_valid / tot_t, 1), "padded_frames_per_s": round(tot_padded / tot_t, 1),
                "ms_per_step_mean": round(tot_t / len(pick) * 1e3, 3),

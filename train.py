@@ -48,7 +48,11 @@ def main(args, configs):
 
     dataset = Dataset("train.txt", preprocess_config, train_config, sort=True, drop_last=True)
     batch_size = train_config["optimizer"]["batch_size"]
-    group_size = 4                                      # sort inside windows of 4 (x world) batches, as train.py:31
+    # sort inside windows of `group_size` (x world) batches: 4 = the reference's own value (train.py:31), the default.  A wider
+    # window leaves less padding per batch (LibriTTS-shaped pool, epoch-wide valid mel rows 0.76 / 0.89 / 0.92 at 4 / 16 / 64) but
+    # buys only +3.5 % frames/s at 64: a B = 48 step of short utterances sits at the ~4.3 ms issue floor whatever its padding
+    # (profiles/r06c_libritts_sweep.log) - and it changes which utterances share a batch, so it stays opt-in
+    group_size = getattr(args, "group_size", 4)
     assert batch_size * group_size * world < len(dataset) or len(dataset) >= batch_size * world
     sampler = BucketedBatchSampler([dataset.length(i) for i in range(len(dataset))], batch_size, world, rank, group_size,
                                    shuffle=True, seed=train_config.get("seed", 1234))
@@ -151,6 +155,7 @@ def parse_args(argv=None):
     parser.add_argument("--dtype", default=None, choices=[None, "fp32", "bf16"],
                         help="compute dtype of the HIP engine (default: FS2_DTYPE or fp32; master weights are always fp32)")
     parser.add_argument("--hifigan_dir", default="hifigan")
+    parser.add_argument("--group_size", type=int, default=4, help="sorting window of the batch sampler in batches (reference train.py:31: 4)")
     parser.add_argument("--hw_queues", type=int, default=fastspeech2_amd.HW_QUEUES_DEFAULT,
                         help="HIP hardware queues of this process (GPU_MAX_HW_QUEUES; the runtime default 4 makes streams share queues: "
                              "utils.SynthPipeline / the engine's side streams); the same for every world size; an exported value wins; 0 = leave the runtime default")
