@@ -186,25 +186,30 @@ def make_step(model, loss_fn, opt, b, exchange):
     return step, fwd_bwd
 
 
-def capture_graph(model, opt, fwd_bwd):
+def capture_graph(model, opt, fwd_bwd, fork=False):
     """hipGraph of forward + loss + backward + clip/Adam (lr / bias corrections are read from device memory).  Returns
     (graph, static_loss, replay) - `replay()` advances the host-side optimiser state and replays.  The caller must have set
     model._engine.device_seed = True BEFORE its warm-up steps: the dropout position then lives in device memory and is bumped
     by a kernel inside the graph (every replay draws fresh masks); an eager-mode capture would bake one step's seed into the
     kernel arguments.  BatchNorm's backward workspaces are cleared inside the capture (engine.py), so replays do not
-    accumulate into each other."""
+    accumulate into each other.
+    fork = False: ONE stream inside the capture (Engine._side_begin enforces that while a capture is in progress).
+    fork = True: the weight-gradient / variance-predictor branches fork onto the side stream INSIDE the capture, as the eager
+    step does (Engine.fork_in_capture).  Rounds 3-5 measured such a capture 2.8e-3 away from the eager gradients; round 6 found
+    the cause (a redundant event recorded on the capture's origin stream from inside a branch section, Engine._wgrad) and
+    tests/test_graph_gpu.py::test_forked_capture_* holds it to the eager step now."""
     assert model._engine.device_seed, "set model._engine.device_seed = True before warm-up and capture"
-    # ONE stream inside the capture: with the weight-gradient / variance-predictor branches forked onto the side stream inside a
-    # capture, replays came out with gradients 2.8e-3 (relative, Adam first moments after 4 replays) away from the eager steps
-    # (tests/test_graph_gpu.py, round 3; single-stream capture matches to 1e-6), and the forked capture was also the slowest
-    # variant (DESIGN §3: 16.9 ms vs 11.6 single-stream vs 9.3 eager with the side stream) - so the graph path does not fork.
-    # (Engine._side_begin enforces that itself while a capture is in progress; the caller's setting is left as it was)
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad()
     torch.cuda.synchronize()
-    with torch.cuda.graph(graph):
-        static_loss = fwd_bwd()
-        opt.apply_update(zero_grad=True)
+    was = model._engine.fork_in_capture
+    model._engine.fork_in_capture = bool(fork)
+    try:
+        with torch.cuda.graph(graph):
+            static_loss = fwd_bwd()
+            opt.apply_update(zero_grad=True)
+    finally:
+        model._engine.fork_in_capture = was
     torch.cuda.synchronize()
 
     def replay():
@@ -836,7 +841,7 @@ def main():
     # after it).  The same step as ONE captured hipGraph, reported BESIDE the eager number (VERDICT r03 missing 6): ~290 dependent launches per
     # step replayed without host dispatch - but on one stream (a forked capture was slower and less accurate, capture_graph), so the
     # weight gradients no longer overlap the data-gradient chain.  `value` stays the eager step, which is what train.py runs.
-    graph_ms = None
+    graph_ms = graph_fork_ms = None
     if graph is None and not pg and args.dtype == "bf16" and not args.no_graph_line:
         seed_was = model._engine.device_seed
         try:
@@ -844,16 +849,19 @@ def main():
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
-            g2, _sl, replay2 = capture_graph(model, opt, fwd_bwd)
-            for _ in range(3):
-                replay2()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                replay2()
-            torch.cuda.synchronize()
-            graph_ms = (time.perf_counter() - t0) / args.steps * 1e3
-            del g2
+            res = []
+            for fork in (False, True):          # one stream inside the capture | branches forked inside it, as the eager step runs
+                g2, _sl, replay2 = capture_graph(model, opt, fwd_bwd, fork=fork)
+                for _ in range(3):
+                    replay2()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    replay2()
+                torch.cuda.synchronize()
+                res.append((time.perf_counter() - t0) / args.steps * 1e3)
+                del g2
+            graph_ms, graph_fork_ms = res
         except Exception as e:  # a measurement aid: never fails the line
             print(f"[bench] hipGraph side measurement failed ({type(e).__name__}: {e})", file=sys.stderr)
         model._engine.device_seed = seed_was
@@ -871,6 +879,7 @@ def main():
                        "valid_row_fraction": round(frames.item() / padded.item(), 4),
                        **({"sampler_group_size": args.group_size} if args.workload == "libritts" else {}),
                        **({"hip_graph_ms_per_step": round(graph_ms, 3)} if graph_ms is not None else {}),
+                       **({"hip_graph_forked_ms_per_step": round(graph_fork_ms, 3)} if graph_fork_ms is not None else {}),
                        "padded_frames_per_s": round(padded.item() * args.steps / dt, 1), "final_loss": round(final_loss, 4),
                        "side_stream_wgrad": bool(args.side_stream) and graph is None, **({"host_issue_ms_per_step": round(host_ms, 3)} if host_ms else {}),
                        "windows": len(window_s), "window_ms_per_step": [round(w / args.steps * 1e3, 3) for w in window_s],

@@ -85,6 +85,7 @@ class Engine:
         # the device tensors (`_fs2_host`, lost by .to() / clone / slicing, stale when a static buffer is refilled with copy_)
         self.length_hint = None
         self._wgrad_ws = ops.WgradWorkspaces()      # split-K scratch of the weight gradients: lives and dies with this engine
+        self.fork_in_capture = False    # debug / measurement switch: let the side stream fork INSIDE a hipGraph capture (tools/dbg_fork_capture.py)
         self.res_in_ln = True           # see _fft_bwd: residual-branch gradients are added by the LayerNorm backward below, not by the dgrad epilogue
         self.fuse_proj_ln = False       # see _proj_ln: True = every N = 256 projection, "stream" = only where the streaming kernel runs it
         self._pack_pending = False
@@ -393,7 +394,7 @@ class Engine:
         """side stream available for branch concurrency (creates it)"""
         if not (self.use_side_stream and self.concurrent_branches) or self.device.type != "cuda":
             return False
-        if torch.cuda.is_current_stream_capturing():        # one stream inside a capture (see _side_begin)
+        if torch.cuda.is_current_stream_capturing() and not self.fork_in_capture:        # one stream inside a capture (see _side_begin)
             return False
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
@@ -411,7 +412,12 @@ class Engine:
         if side is None:
             ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb, ws_owner=self._wgrad_ws)
             return
-        side.wait_stream(self._main)            # dy was produced on the main stream
+        if not self._on_side:
+            # dy was produced on the main stream.  NOT inside a branch section: there the launches already run on the side stream,
+            # dy was produced on it, and an event recorded on the capture's origin stream from inside the section made a forked
+            # hipGraph capture lose the origin stream's edge loss_bwd -> bn_bwd_acc (rounds 3-5's "2.8e-3 off" forked capture:
+            # tools/dbg_fork_capture.py poisons every capture-time buffer and names the reader that ran early)
+            side.wait_stream(self._main)
         with ops.pinned_stream(side):           # (no allocation happens inside: only the launch needs the side stream)
             self._ln_flush()
             ops.conv_wgrad(dy, x, gw, S, taps=taps, pad=pad, lens=lens, dbias=gb, ws_owner=self._wgrad_ws)
@@ -441,7 +447,7 @@ class Engine:
         if self._pack_pending:                  # data-gradient packs were written on the side stream during forward
             self._main.wait_stream(self._side_stream)
             self._pack_pending = False
-        if not self.use_side_stream or torch.cuda.is_current_stream_capturing():
+        if not self.use_side_stream or (torch.cuda.is_current_stream_capturing() and not self.fork_in_capture):
             # inside a hipGraph capture the step stays on ONE stream whatever use_side_stream says: a forked capture replayed
             # with gradients 2.8e-3 away from the eager steps (round 3, cause not found) and was the slowest variant anyway
             self._side = None

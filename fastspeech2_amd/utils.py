@@ -218,6 +218,10 @@ class SynthPipeline:
         # voc_streams > 1: consecutive batches' vocoders on alternating streams (the tail of one launch filled by the other batch's)
         self.s_vocs = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(voc_streams)))]
         self._n = 0
+        # pinned PCM staging: a RING of host buffers (one more than the batches in flight), each grown to the largest batch it has
+        # carried - rounds 1-5 asked the pinned allocator for a fresh tensor per batch.  A slot is reused only after the batch that
+        # last used it has been handed to the caller (its `done` event waited for and its samples copied out by _finish)
+        self._pcm_ring = [None] * (len(self.s_vocs) + 2)
         # the vocoder's packed weight images: made once, here, and every stream of the pipeline is ordered behind that (the first
         # forward would otherwise pack them on ITS stream while the next batch's forward reads them on another)
         vocoder.prepare(self.device)
@@ -240,7 +244,11 @@ class SynthPipeline:
             with torch.cuda.stream(s_voc):
                 s_voc.wait_event(ready)
                 pcm = self.vocoder.infer_pcm(out[1].transpose(1, 2), self.preprocess_config["preprocessing"]["audio"]["max_wav_value"])
-                host = torch.empty(pcm.shape, dtype=pcm.dtype, pin_memory=True)
+                slot = (self._n - 1) % len(self._pcm_ring)
+                buf = self._pcm_ring[slot]
+                if buf is None or buf.numel() < pcm.numel():
+                    buf = self._pcm_ring[slot] = torch.empty(max(pcm.numel(), 1 << 20), dtype=pcm.dtype, pin_memory=True)
+                host = buf[:pcm.numel()].view(pcm.shape)
                 host.copy_(pcm, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(s_voc)
@@ -250,7 +258,7 @@ class SynthPipeline:
     def _finish(self, item):
         batch, out, pcm, host, lengths, done = item
         done.synchronize()
-        wavs = [w[:n] for w, n in zip(host.numpy(), lengths)]
+        wavs = [w[:n].copy() for w, n in zip(host.numpy(), lengths)]        # (out of the ring slot: it is reused len(ring) batches later)
         if self.write:
             _write_wavs(self.path, batch[0], wavs, self.preprocess_config)
         return batch, out, wavs
