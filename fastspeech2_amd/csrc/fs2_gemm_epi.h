@@ -9,8 +9,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // epilogue straight from the transposed accumulators: lane (fl, fh) holds, for row m = mbase + fl, the columns
 // nb*32 + 8*g + 4*fh + e (g = r>>2, e = r&3).  v_permlane32_swap pairs (g, g+1) across the two half-waves so that a lane ends
 // up with columns nb*32 + fh*8 + [0,8) (from g = 0,1) and nb*32 + 16 + fh*8 + [0,8) (from g = 2,3): two 16-byte bf16 runs.
-template <int ACT>
-__device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[2][4], int m0, int n0, int wm, int fl, int fh,
+// MB = 32-row blocks a wave owns (2: the 64 x 128 wave tile; 1: 32 x 128, the twelve-wave form of the persistent kernel); wave wm's rows start at wm * 32 * MB
+template <int ACT, int MB>
+__device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[MB][4], int m0, int n0, int wm, int fl, int fh,
                                            const int32_t* lens_s, float* bias_s, int lane) {
     bf16_t* Y = reinterpret_cast<bf16_t*>(a.Y);
     const bf16_t* R = reinterpret_cast<const bf16_t*>(a.R);
@@ -26,8 +27,8 @@ __device__ __forceinline__ void p_epilogue(const ConvGemmArgs& a, f32x16 (&acc)[
         }
     }
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int m = m0 + wm * 64 + mb * 32 + fl;
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = m0 + wm * (32 * MB) + mb * 32 + fl;
         const bool rowok = m < a.M;
         bool padrow = false;
         if (a.lens && rowok) { const int b = m / a.S; padrow = (m - b * a.S) >= lens_s[b]; }

@@ -70,7 +70,7 @@ __device__ __forceinline__ const unsigned char* p_uniform(const unsigned char* q
 }
 template <int N> __device__ __forceinline__ void p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 static constexpr int P_MAXB = 1024;                       // lens[] staged in LDS
-static constexpr int P_AUX_BYTES = P_MAXB * 4 + 4 * 512;  // lens + one 128-float bias line per consumer wave
+static constexpr int P_AUX_BYTES = P_MAXB * 4 + 8 * 512;  // lens + one 128-float bias line per consumer wave (4 or 8 of them)
 static constexpr int P_B_BYTES = 128 * 128;
 
 __device__ __forceinline__ int p_ntiles(const PSched& s) {
@@ -221,11 +221,12 @@ __device__ __forceinline__ void p_loader(const ConvGemmArgs& a, const PSched& sc
 // into one shared M x N slab with float atomics: a lane owns a ROW there, so every atomic instruction touched 64 different
 // cache lines (r02f: 48 tiles x 144 K-steps ran 100 us unsplit, 131 us at 2 splits, 185 us at 4).  Bias / activation /
 // residual happen once, in splitk_finalize_kernel, which also sums the slabs.
-__device__ __forceinline__ void p_epilogue_splitk(const ConvGemmArgs& a, float* ws, f32x16 (&acc)[2][4], int m0, int n0, int wm,
+template <int MB>
+__device__ __forceinline__ void p_epilogue_splitk(const ConvGemmArgs& a, float* ws, f32x16 (&acc)[MB][4], int m0, int n0, int wm,
                                                   int fl, int fh) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int m = m0 + wm * 64 + mb * 32 + fl;
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = m0 + wm * (32 * MB) + mb * 32 + fl;
         if (m >= a.M) continue;
         float* wrow = ws + (size_t)m * a.N;
 #pragma unroll
@@ -297,10 +298,11 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(ConvGemmArgs a, co
 }
 
 // tail part: the partial 256x128 tile goes to the workgroup's slab, tile-local row-major (row = wm*64 + mb*32 + fl)
-__device__ __forceinline__ void p_epilogue_part(float* slab, f32x16 (&acc)[2][4], int wm, int fl, int fh) {
+template <int MB>
+__device__ __forceinline__ void p_epilogue_part(float* slab, f32x16 (&acc)[MB][4], int wm, int fl, int fh) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        float* wrow = slab + (size_t)(wm * 64 + mb * 32 + fl) * 128;
+    for (int mb = 0; mb < MB; ++mb) {
+        float* wrow = slab + (size_t)(wm * (32 * MB) + mb * 32 + fl) * 128;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             float c[2][8];
@@ -396,7 +398,10 @@ __device__ __forceinline__ u32x4 p_lrelu(u32x4 v, float slope) {
 }
 
 // ABL bit 16 (shipped): leaky-ReLU prologue on the activation fragments.  Other ABL bits (dev builds only): 1 = no MFMA, 2 = no fragment reads, 4 = no epilogue
-template <bool ONE_TAP, bool WIDE, int ABL>
+// MB = 2: four consumer waves of 64 x 128 (one per SIMD beside its loader wave); MB = 1: EIGHT consumer waves of 32 x 128 (two per
+// SIMD: while one waits for a fragment or at its counted lgkmcnt the other issues MFMAs - the lone wave's in-order issue of reads
+// and MFMAs was this kernel's measured limiter, see the header) at 5 fragment reads per 4 MFMAs instead of 6 per 8
+template <bool ONE_TAP, bool WIDE, int ABL, int MB>
 __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& sc, unsigned char* smem, int lane, int wm,
                                            const PUnits& units, int ntiles, const int32_t* lens_s, float* bias_s) {
     typedef PCfg<ONE_TAP, WIDE> C;
@@ -414,13 +419,13 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
     const unsigned c0 = (unsigned)(fh * 4);
     const unsigned ckb = c0 ^ (unsigned)((fl >> 1) & 7);                     // weight rows are never shifted
     const unsigned blane = smem_u + C::B_OFF + (unsigned)(fl * 128);
-    const unsigned alane = smem_u + (unsigned)((wm * 64 + fl) * 128);
+    const unsigned alane = smem_u + (unsigned)((wm * (32 * MB) + fl) * 128);
     auto a_base = [&](int abuf, int tap) -> unsigned { return alane + (unsigned)(abuf * C::A_BYTES + tap * a.dil * 128); };
     auto a_key = [&](int tap) -> unsigned { return c0 ^ (unsigned)(((fl + tap * a.dil) >> 1) & 7); };   // key of the PHYSICAL halo row
     auto b_base = [&](int slot) -> unsigned { return blane + (unsigned)(slot * P_B_BYTES); };
 
-    u32x4 Af[2][2], Bf[2][4];                                // [set][mb], [set][nb]: fragment double buffer
-    f32x16 acc[2][4];
+    u32x4 Af[2][MB], Bf[2][4];                               // [set][mb], [set][nb]: fragment double buffer
+    f32x16 acc[MB][4];
 
     // one k-slice: 8 MFMAs of fragment set SET, the six reads of the NEXT slice (k-slice JN of the step whose operands sit at
     // ABASE / AKEY / BBASE, into set SET^1) issued one behind each of the first six MFMAs.
@@ -460,16 +465,53 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         FS2P_MFMA(SET, 1, 3, av1); FS2P_FENCE();                                                                            \
     } while (0)
 
+    // MB == 1: 4 MFMAs per k-slice, the FIVE reads of the next slice in the order A0 B0 B1 B2 B3; MFMA i needs read i + 1 of the
+    // five issued a slice ago: "at most 3 younger LDS reads outstanding" at every position
+#define FS2P_SLICE1(SET, MASKED, LIVE0, DO_READS, JN, ABASE, AKEY, BBASE)                                                   \
+    do {                                                                                                                    \
+        u32x4 av0;                                                                                                          \
+        FS2P_WAIT_LGKM(3); FS2P_FENCE();                                                                                    \
+        av0 = Af[SET][0]; if (ABL & 16) av0 = p_lrelu(av0, a.in_slope);                                                     \
+        if (MASKED && !(LIVE0)) av0 = u32x4{0u, 0u, 0u, 0u};                                                                \
+        FS2P_MFMA(SET, 0, 0, av0); FS2P_FENCE();                                                                            \
+        const unsigned aa_ = (ABASE) + ((((AKEY)) ^ (unsigned)(JN)) << 4);                                                  \
+        const unsigned ba_ = (BBASE) + ((ckb ^ (unsigned)(JN)) << 4);                                                       \
+        if (DO_READS) { FS2P_DS_READ(Af[SET ^ 1][0], aa_, 0); } FS2P_FENCE();                                               \
+        FS2P_WAIT_LGKM(3); FS2P_FENCE();                                                                                    \
+        FS2P_MFMA(SET, 0, 1, av0); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][0], ba_, 0); } FS2P_FENCE();                                               \
+        FS2P_WAIT_LGKM(3); FS2P_FENCE();                                                                                    \
+        FS2P_MFMA(SET, 0, 2, av0); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][1], ba_, 4096); } FS2P_FENCE();                                            \
+        FS2P_WAIT_LGKM(3); FS2P_FENCE();                                                                                    \
+        FS2P_MFMA(SET, 0, 3, av0); FS2P_FENCE();                                                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][2], ba_, 8192); } FS2P_FENCE();                                            \
+        if (DO_READS) { FS2P_DS_READ(Bf[SET ^ 1][3], ba_, 12288); } FS2P_FENCE();                                           \
+    } while (0)
+    // the slice of this instantiation (the other macro's body is discarded by the if constexpr)
+#define FS2P_SL(SET, MASKED, LIVE0, LIVE1, DO_READS, JN, ABASE, AKEY, BBASE)                                                \
+    do {                                                                                                                    \
+        if constexpr (MB == 2) { FS2P_SLICE(SET, MASKED, LIVE0, LIVE1, DO_READS, JN, ABASE, AKEY, BBASE); }                 \
+        else { FS2P_SLICE1(SET, MASKED, LIVE0, DO_READS, JN, ABASE, AKEY, BBASE); }                                         \
+    } while (0)
+
+    auto land_set0 = [&]() {                                 // lgkmcnt(0) with fragment set 0 as its OUTPUTS (see the two call sites)
+        if constexpr (MB == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
+    };
     int gs = 0, gc = 0, slot = 0;                            // global step / chunk, ring slot of step gs
     FS2P_WAIT_LGKM(0);                                       // kernel arguments, lens staging: lgkmcnt is ours from here
     __builtin_amdgcn_s_barrier();                            // slot(0) published
     if (!(ABL & 2)) {
         const unsigned aa = a_base(0, 0) + (a_key(0) << 4), ba = b_base(0) + (ckb << 4);
         FS2P_DS_READ(Af[0][0], aa, 0); FS2P_DS_READ(Bf[0][0], ba, 0); FS2P_DS_READ(Bf[0][1], ba, 4096);
-        FS2P_DS_READ(Bf[0][2], ba, 8192); FS2P_DS_READ(Bf[0][3], ba, 12288); FS2P_DS_READ(Af[0][1], aa, 4096);
+        FS2P_DS_READ(Bf[0][2], ba, 8192); FS2P_DS_READ(Bf[0][3], ba, 12288);
+        if constexpr (MB == 2) FS2P_DS_READ(Af[0][1], aa, 4096);
         // these six sit outside the tile loop: have them LANDED before the compiler may copy their registers into the
         // loop-carried ones (a copy of a register with a read in flight would carry stale data)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
+        land_set0();
     }
     for (int k = 0; k < ntiles; ++k) {
         int mt, nt, kc0_unused;
@@ -483,8 +525,8 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         if (!ONE_TAP) {
             const unsigned full = (taps >= 32) ? 0xffffffffu : ((1u << taps) - 1u);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int m = m0 + wm * 64 + mb * 32 + fl;
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = m0 + wm * (32 * MB) + mb * 32 + fl;
                 unsigned msk = 0;
                 if (m < a.M) {
                     const int t = m % a.S;
@@ -499,7 +541,7 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
             need_mask = __builtin_amdgcn_ballot_w64(need_mask) != 0ull;      // wave-uniform
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -507,15 +549,20 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
 
         auto run_tile = [&](auto maskc) {
             constexpr bool MASKED = decltype(maskc)::value;
-            for (int kc = 0; kc < nkc_k; ++kc) {
-                for (int tap = 0; tap < taps; ++tap) {
+            // ONE loop over the unit's K-steps (chunk-major, taps inside a chunk).  As two nested loops the compiler gave the inner loop its
+            // own registers for the loop-carried fragment set and COPIED the outer loop's into them at the inner loop's entry - with the
+            // reads of that set still in flight (stale copies: the eight-wave form's last-issued fragment came out wrong in a timing-
+            // dependent 1 % of the outputs).  tools/check_frag_copies.py scans the ISA for such copies.
+            int tap = 0;
+            for (int st = 0, nst = nkc_k * taps; st < nst; ++st) {
+                {
                     const int abuf = ONE_TAP ? slot : (gc & 1);
                     const bool live0 = (vmask[0] >> tap) & 1u, live1 = (vmask[1] >> tap) & 1u;
                     const bool more = gs + 1 < total;                       // another step follows (this tile or the next)
                     const unsigned ab = a_base(abuf, tap), ak = a_key(tap), bb = b_base(slot);
-                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 1, ab, ak, bb);
-                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 2, ab, ak, bb);
-                    FS2P_SLICE(0, MASKED, live0, live1, !(ABL & 2), 3, ab, ak, bb);
+                    FS2P_SL(0, MASKED, live0, live1, !(ABL & 2), 1, ab, ak, bb);
+                    FS2P_SL(1, MASKED, live0, live1, !(ABL & 2), 2, ab, ak, bb);
+                    FS2P_SL(0, MASKED, live0, live1, !(ABL & 2), 3, ab, ak, bb);
                     FS2P_WAIT_LGKM(0); FS2P_FENCE();                        // every read of slot(gs) / its halo tile has landed
                     if (more) __builtin_amdgcn_s_barrier();                 // slot(gs+1) published, slot(gs) released
                     FS2P_FENCE();
@@ -526,8 +573,8 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
                     // (after the workgroup's very last step these six reads fetch operands nobody uses: issuing them unconditionally keeps the
                     // fragment registers single-definition - a conditional read would make the compiler merge two register sets with
                     // copies, and a copy of a register with a read in flight carries stale data)
-                    FS2P_SLICE(1, MASKED, live0, live1, !(ABL & 2), 0, nab, nak, nbb);
-                    ++gs; slot = nslot; gc = ngc;
+                    FS2P_SL(1, MASKED, live0, live1, !(ABL & 2), 0, nab, nak, nbb);
+                    ++gs; slot = nslot; gc = ngc; tap = ntap;
                 }
             }
         };
@@ -537,30 +584,33 @@ __device__ __forceinline__ void p_consumer(const ConvGemmArgs& a, const PSched& 
         // COPY those registers at a unit boundary - and a copy of a register whose read is still in flight carries stale data
         // (seen in the round-2 "v3" experiment: whole 32-row blocks of the last-issued fragment wrong in a few tiles).  Land
         // them first, AS OUTPUTS of the wait, so every copy is ordered behind it (one LDS drain per tile, not per step).
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Bf[0][0]), "+v"(Bf[0][1]), "+v"(Bf[0][2]), "+v"(Bf[0][3]) :: "memory");
+        land_set0();
 
         if (nparts > 1) {
             p_epilogue_part(sc.tws + (size_t)sc.b * (256 * 128), acc, wm, fl, fh);
         } else if (sc.ks > 1) {
             p_epilogue_splitk(a, sc.ws + (size_t)split * a.M * a.N, acc, m0, n0, wm, fl, fh);
         } else if (!(ABL & 4)) {
-            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, m0, n0, wm, fl, fh, lens_s, bias_s, lane)));
+            FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT, MB>(a, acc, m0, n0, wm, fl, fh, lens_s, bias_s, lane)));
         } else {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s += acc[i][j][0];
             if (s == 12345.678f) reinterpret_cast<bf16_t*>(a.Y)[0] = 0;
         }
         if (ABL & 2) asm volatile("" :: "v"(Af[0][0]), "v"(Bf[0][0]));
     }
+#undef FS2P_SL
+#undef FS2P_SLICE1
 #undef FS2P_SLICE
 #undef FS2P_MFMA
 }
 
-template <bool ONE_TAP, bool WIDE, int ABL>
-__global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSched sc0) {
+// CW consumer waves (4: 64 x 128 each, 512 threads, 256 registers per wave; 8: 32 x 128 each, 768 threads, 168 registers) + 4 loader waves
+template <bool ONE_TAP, bool WIDE, int ABL, int CW>
+__global__ void __launch_bounds__(CW * 64 + 256, (CW + 4) / 4) conv_gemm_p_kernel(ConvGemmArgs a, PSched sc0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef PCfg<ONE_TAP, WIDE> C;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -572,16 +622,16 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
         sc.n_pad = sc.ntm - sc.n_real;
     }
     int32_t* lens_s = reinterpret_cast<int32_t*>(smem + C::AUX);
-    float* bias_s = reinterpret_cast<float*>(smem + C::AUX + P_MAXB * 4) + (wave & 3) * 128;
+    float* bias_s = reinterpret_cast<float*>(smem + C::AUX + P_MAXB * 4) + (wave & 7) * 128;     // (consumer waves only)
     const int ntiles = p_ntiles(sc);                         // 0 when every real tile went to other workgroups
     // this workgroup's units (loaded separately in the two roles: a wave keeps its own packed copy in two VGPRs)
     PUnits units;
     p_units_load(sc, lane, units);
-    if (wave < 4) {
+    if (wave < CW) {
         // per-sequence lengths -> LDS (the epilogue's padded-row test must not wait on global memory behind its own stores)
         if (a.lens) {
             const int B = a.M / a.S;
-            for (int i = tid; i < B; i += 256) lens_s[i] = a.lens[i];
+            for (int i = tid; i < B; i += CW * 64) lens_s[i] = a.lens[i];
         }
         // fully padded tiles of this workgroup: zeros (while the loaders fill the rings)
         if (!a.accumulate && sc.n_pad > 0 && sc.ks == 1) {      // (K-split launches: splitk_finalize_kernel writes every row)
@@ -590,7 +640,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
             for (int p = sc.b; p < n_pu; p += sc.G) {
                 const int nt = p / sc.n_pad, pi = p - nt * sc.n_pad;
                 const int m0 = sc.tmap[1 + sc.n_real + pi] * 256, n0 = nt * 128;
-                for (int i = tid; i < 256 * 16; i += 256) {
+                for (int i = tid; i < 256 * 16; i += CW * 64) {
                     const int m = m0 + (i >> 4), n = n0 + (i & 15) * 8;
                     if (m < a.M && n < a.N) *reinterpret_cast<uint4*>(Y + (size_t)m * a.ldy + n) = make_uint4(0, 0, 0, 0);
                 }
@@ -599,9 +649,9 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_p_kernel(ConvGemmArgs a, PSc
         // the four consumer waves make the staged lengths visible to each other before anyone's epilogue: they all pass
         // the per-step barriers (>= 1) before the first epilogue, and LDS writes are ordered ahead of the wave's barrier
         // arrival by the s_waitcnt lgkmcnt(0) in front of the first barrier.
-        if (ntiles > 0) p_consumer<ONE_TAP, WIDE, ABL>(a, sc, smem, lane, wave, units, ntiles, lens_s, bias_s);
+        if (ntiles > 0) p_consumer<ONE_TAP, WIDE, ABL, 8 / CW>(a, sc, smem, lane, wave, units, ntiles, lens_s, bias_s);
     } else if (ntiles > 0) {                                 // (a workgroup without real tiles runs no barrier on either side)
-        p_loader<ONE_TAP, WIDE>(a, sc, smem, lane, wave - 4, units, ntiles);
+        p_loader<ONE_TAP, WIDE>(a, sc, smem, lane, wave - CW, units, ntiles);
     }
 }
 
@@ -713,12 +763,26 @@ static int fs2_cu_count() {
     return cus[d];
 }
 
-template <bool ONE_TAP, bool WIDE, int ABL>
-static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream) {
+template <bool ONE_TAP, bool WIDE, int ABL, int CW>
+static void launch_p_cw(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream) {
     constexpr int dyn = PCfg<ONE_TAP, WIDE>::AUX + P_AUX_BYTES;
     static Fs2DevOnce once;
-    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_p_kernel<ONE_TAP, WIDE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
-    conv_gemm_p_kernel<ONE_TAP, WIDE, ABL><<<(unsigned)sc.G, 512, dyn, stream>>>(a, sc);
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_gemm_p_kernel<ONE_TAP, WIDE, ABL, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
+    conv_gemm_p_kernel<ONE_TAP, WIDE, ABL, CW><<<(unsigned)sc.G, CW * 64 + 256, dyn, stream>>>(a, sc);
+}
+// Consumer-wave count per launch (r06j / r06k same-box A/B, profiles/r06j_bench_p_cw.log): eight 32 x 128 waves win where the epilogue
+// is a large share of a unit - N >= 1024 forward convolutions, 36 K-steps per 256 x 128 unit: k = 9 FFN forward 227 -> 211 us, the
+// encoder's 38.1 -> 35.8 - and lose a little on long reductions (k = 9 data gradient, 144 steps per unit: 195.6 -> 200.9 us);
+// PostNet / one-tap shapes are within noise.  The ablations say why it is not more: loaders alone 86 us, MFMAs + loaders 154,
+// reads + loaders 121, everything 218 - DMA and MFMA time largely ADD at the per-step barrier, whoever issues the MFMAs.
+template <bool ONE_TAP, bool WIDE, int ABL>
+static void launch_p(const ConvGemmArgs& a, const PSched& sc, hipStream_t stream) {
+    if constexpr (!ONE_TAP && !WIDE) {
+        static const int cw_env = fs2_dev_env("FS2_P_CW", 0);
+        const int cw = cw_env ? cw_env : (a.N >= 1024 ? 8 : 4);
+        if (cw == 8) { launch_p_cw<ONE_TAP, WIDE, ABL, 8>(a, sc, stream); return; }
+    }
+    launch_p_cw<ONE_TAP, WIDE, ABL, 4>(a, sc, stream);
 }
 
 // bytes of tail-split scratch fs2_conv_gemm_tail wants: one f32 256 x 128 tile slab per workgroup of a full-chip launch

@@ -304,7 +304,7 @@ __device__ __forceinline__ void conv_gemm_w_body(const ConvGemmArgs& a, const WS
             if (RESLN) {
                 w_epilogue_resln(a, ln, acc, q[0].mt * 256, wave, wm, wn, fl, fh, lens_s, reinterpret_cast<float*>(smem + W_AUX + W_MAXB * 4));
             } else {
-                FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT>(a, acc, q[0].mt * 256, q[0].nt * 256 + wn * 128, wm, fl, fh, lens_s, bias_s, lane)));
+                FS2_ACT_DISPATCH(a.act, (p_epilogue<ACT, 2>(a, acc, q[0].mt * 256, q[0].nt * 256 + wn * 128, wm, fl, fh, lens_s, bias_s, lane)));
             }
             zero_acc();
         }
