@@ -12,6 +12,8 @@
 // regs = rows (r&3)+8*(r>>2)+4*(lane>>5);  A layout: lane = row, k-slot = lane>>5) -> P never leaves registers.
 // Storage dtype T may be bf16; tiles are widened to f32 when staged into LDS (first revision: f32 MFMA rate).
 #include "fs2_common.h"
+#include "fs2_gemm.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -529,6 +531,311 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
     }
 }
 
+// ---- dK, dV, second form (round 6): the same tiles, fragments and arithmetic, SOFTWARE-PIPELINED inside the wave.
+// The first form runs one wave per SIMD (128 accumulator registers + 64 of K / V fragments leave no room for a second), and that
+// wave walked S^T / dP^T MFMAs -> exponentials -> dV / dK MFMAs strictly one after the other, each phase behind the LDS round
+// trip of its fragments: 133 us per decoder layer at 17 % MFMA busy (r05zzz PMC) - 7 350 cycles per 64-query tile for 2 048 cycles
+// of MFMA.  Here the two 32-query blocks of a tile are skewed by one phase, so that every VALU phase has an independent MFMA run
+// to hide under and every fragment batch is requested one 8-MFMA run (256 cycles) before its use:
+//     A0a | A0b | A1a + B0' | A1b + B0" | C0a + B1' | C0b + B1" | C1a | C1b          (A: S^T, dP^T; B: p, dS; C: dV, dK)
+// The interleave inside a run is pinned with sched_group_barrier (one MFMA, then its share of the VALU / transcendental / LDS
+// instructions); sched_barrier(0) separates the runs.  A block whose queries all lie beyond the sequence is multiplied anyway
+// (its lse is +inf -> p = 0 exactly): no branch inside the tile.  Fragment addresses are lane constants (16 registers) with the
+// buffer / array / row-block as immediate offsets - the tile loop is unrolled over the two LDS buffers.
+#define FS2_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#define FS2_SG_MFMA 0x008
+#define FS2_SG_VALU 0x002
+#define FS2_SG_TRANS 0x400
+#define FS2_SG_DSR 0x100
+#define FS2_SG_DSW 0x200
+#ifdef FS2_DEV
+// dev builds: s_memtime stamps of workgroup (0, 0, 0), wave 0 at the phase boundaries of its first tiles (tools/attn_phases.py)
+__device__ unsigned long long fs2_attn_stamps[16 * 12];
+extern "C" int fs2_dev_attn_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs2_attn_stamps), sizeof(fs2_attn_stamps)) == hipSuccess ? 0 : 1;
+}
+#define FS2_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && q0 < 16 * 64) fs2_attn_stamps[(q0 >> 6) * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FS2_STAMP(i) do {} while (0)
+#endif
+__global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                                    const bf16_t* __restrict__ dctx, long ldo,
+                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                    bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,
+                                                                    int S, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char sQD[2][2][64 * 256];   // [buffer][Q | dO]
+    __shared__ __attribute__((aligned(16))) float sLD[2][2][64];                 // [buffer][lse | delta] of the tile's queries
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(lens[b], S) : S;
+    const size_t rowbase = (size_t)b * S;
+    const int kbase = kt * 128 + w * 32;
+    bf16_t* dK = dqkv + rowbase * ld + (size_t)H * DK + h * DK;
+    bf16_t* dV = dqkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    if (kt * 128 >= len) {
+        for (int i = tid; i < 128 * 32; i += 256) {
+            int r = i >> 5, c = (i & 31) * 4;
+            if (kt * 128 + r < S) {
+                st4<bf16_t>(dK + (size_t)(kt * 128 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+                st4<bf16_t>(dV + (size_t)(kt * 128 + r) * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+        return;
+    }
+    const bf16_t* Q = qkv + rowbase * ld + h * DK;
+    const bf16_t* K = qkv + rowbase * ld + (size_t)H * DK + h * DK;
+    const bf16_t* V = qkv + rowbase * ld + (size_t)2 * H * DK + h * DK;
+    const bf16_t* dO = dctx + rowbase * ldo + h * DK;
+    const float* lse_b = lse + ((size_t)b * H + h) * S;
+    const float* del_b = delta + ((size_t)b * H + h) * S;
+    const int mykey = kbase + fl;
+    bf16x8 kf[8], vf[8];
+    load_row_frags(kf, K + (size_t)min(mykey, S - 1) * ld, h2, mykey < S);
+    load_row_frags(vf, V + (size_t)min(mykey, S - 1) * ld, h2, mykey < S);
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[nb][r] = 0.f; dv[nb][r] = 0.f; }
+    const float* ld_src = tid < 64 ? lse_b : del_b;
+    const float sc2 = scale * 1.4426950408889634f;
+    // the raw value is LOADED at the top of a tile and CONVERTED where it is stored (end of the tile): the first form multiplied it
+    // right behind the load - an s_waitcnt vmcnt(0) at the top of every tile, which also waited for the tile's own prefetch: a full
+    // memory round trip per tile in front of everything else (r06n PMC: 41 % of the wave time parked)
+    // (an asm load: the compiler sinks a plain load down to its use - issued late, waited for at once; nothing but the explicit
+    // s_waitcnt vmcnt(0) in front of the tile's closing barrier may wait on vector memory inside the loop, because the counter also
+    // holds the tile's LDS-DMA pieces)
+    auto load_ld = [&](int q0) -> float {
+        float v;
+        const float* pa_ = ld_src + min(q0 + (tid & 63), S - 1);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(pa_) : "memory");
+        return v;
+    };
+    auto conv_ld = [&](float v, int q0) -> float {
+        const int q = q0 + (tid & 63);
+        if (tid < 64) v *= 1.4426950408889634f;
+        if (q >= len) v = tid < 64 ? INFINITY : 0.f;
+        return v;
+    };
+    // fragment addresses: LDS byte addresses of this lane's pieces in the CURRENT buffer's Q image (the dO image, the row block and the
+    // d-slice enter as immediate offsets); they flip between the two buffers by +- 32 KiB at the end of every tile (16 adds per tile
+    // instead of ~80 address instructions per tile in the first form)
+    const unsigned lds_qd = lds_addr(&sQD[0][0][0]);
+    unsigned ak[8], at0[4], at1[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ak[i] = lds_qd + (unsigned)swzb(fl, 2 * i + h2);
+    {
+        const int li = lane & 15, g = lane >> 4, hh = g >> 1, rr = 4 * hh + (li >> 2);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int col = nb * 32 + 16 * (g & 1) + 4 * (li & 3);
+            at0[nb] = lds_qd + (unsigned)(swzb(rr, col >> 3) + ((col & 7) << 1));
+            at1[nb] = lds_qd + (unsigned)(swzb(rr + 8, col >> 3) + ((col & 7) << 1));
+        }
+    }
+    typedef __attribute__((address_space(3))) const uint4* lds_u4p;
+    // arr: 0 = Q, 1 = dO; qb: 32-query block; i: d-slice
+    auto rdk = [&](int arr, int qb, int i) -> bf16x8 {
+        return __builtin_bit_cast(bf16x8, *(lds_u4p)(size_t)(ak[i] + (unsigned)(arr * 16384 + qb * 8192)));
+    };
+    auto rdt = [&](int arr, int rb, int nb) -> bf16x8 {                            // rb: first of the 16 rows (a multiple of 16)
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(at0[nb] + (unsigned)(arr * 16384 + rb * 256)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(at1[nb] + (unsigned)(arr * 16384 + rb * 256)));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // Tile staging by LDS-DMA (no staging registers, no ds_write pass): a 1 KiB piece = 4 tile rows, lane l -> row l >> 4, LDS chunk
+    // position l & 15, which must hold global chunk (l & 15) ^ S(row) (the swizzle is an involution on the chunk index); wave w moves
+    // pieces w, w + 4, w + 8, w + 12 of Q and of dO.  Rows are clamped to the sequence's last row (finite data times an exact 0).
+    unsigned voq[4], vod[4];            // per piece: byte offset of this lane's 16 bytes relative to (tile row 0) - the row part is added per tile
+    int prow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * (w + 4 * j) + (lane >> 4);
+        const int c = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        prow[j] = row;
+        voq[j] = (unsigned)c * 16u; vod[j] = (unsigned)c * 16u;
+    }
+    auto dma_piece = [&](int q0, int buf, int j) {          // piece w + 4 j of Q and of dO
+        const unsigned r = (unsigned)min(q0 + prow[j], S - 1);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_qd + (unsigned)(buf * 32768 + (w + 4 * j) * 1024));
+        glds16_sbase(r * (unsigned)(ld * 2) + voq[j], Q, dst);
+        glds16_sbase(r * (unsigned)(ldo * 2) + vod[j], dO, dst + 16384u);
+    };
+    auto dma_tile = [&](int q0, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(q0, buf, j);
+    };
+    float tl = 0.f;
+    dma_tile(0, 0);
+    tl = load_ld(0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(tl) :: "memory");
+    if (tid < 128) sLD[0][tid >> 6][tid & 63] = conv_ld(tl, 0);
+    __syncthreads();
+
+    // p, dS of eight (query, my key) pairs -> packed A operands (lse / delta of the lane's queries come from LDS where they are used)
+    auto softmax8 = [&](const f32x16& s, const f32x16& dp, const float* sl, const float* sd, int qb, int u, bf16x8& pa, bf16x8& da) {
+        float4 l4[2], d4[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            l4[g] = *reinterpret_cast<const float4*>(sl + qb * 32 + 8 * (2 * u + g) + 4 * h2);
+            d4[g] = *reinterpret_cast<const float4*>(sd + qb * 32 + 8 * (2 * u + g) + 4 * h2);
+        }
+        float pv[8], dsv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float lq = reinterpret_cast<const float*>(&l4[e >> 2])[e & 3];
+            const float dq_ = reinterpret_cast<const float*>(&d4[e >> 2])[e & 3];
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[8 * u + e], sc2, -lq));     // (a padded KEY only pollutes its own dK / dV rows: zeroed at the store)
+            pv[e] = p;
+            dsv[e] = p * (dp[8 * u + e] - dq_);
+        }
+        pa = pack8(pv); da = pack8(dsv);
+        // (the compiler sinks part of this arithmetic towards its first use, the dV / dK run two phases later; pinning the packed operands
+        // here with an empty asm measured SLOWER - 191.7 vs 185 us for the whole backward, r06m - so the placement is left to it)
+    };
+
+    // dK / dV stay in their accumulation registers at every phase boundary (left alone, the allocator lent 32 of them to the score
+    // accumulators and moved them out and back with ~107 v_accvgpr copies per tile)
+#define FS2_PIN_ACC() asm volatile("" : "+a"(dk[0]), "+a"(dk[1]), "+a"(dk[2]), "+a"(dk[3]), "+a"(dv[0]), "+a"(dv[1]), "+a"(dv[2]), "+a"(dv[3]))
+    // K / V fragments: landed, and known to the compiler's wait-count pass to have landed, before the loop (otherwise it waits for
+    // them - vmcnt(0), i.e. for the tile's DMA too - in front of the second MFMA of EVERY tile)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(kf[i]), "+v"(vf[i]));
+    int buf = 0, flip = 32768;
+    for (int q0 = 0; q0 < len; q0 += 64, buf ^= 1) {
+        const bool more = q0 + 64 < len;
+        FS2_STAMP(0);
+        constexpr int sQ = 0, sdO = 1;
+        const float* sl = sLD[buf][0];
+        const float* sd = sLD[buf][1];
+        bf16x8 x0q[4], x0d[4], y0q[4], y0d[4], x1q[4], x1d[4], y1q[4], y1d[4];      // K-contiguous batches: block 0 / 1, d-slices 0-3 / 4-7
+        bf16x8 t0d[4], t0q[4], u0d[4], u0q[4], t1d[4], t1q[4], u1d[4], u1q[4];      // transposed batches: block 0 / 1, queries 0-15 / 16-31
+        f32x16 s0, p0, s1, p1;
+        bf16x8 pa0a, da0a, pa0b, da0b, pa1a, da1a, pa1b, da1b;
+        // the tile's first fragments are requested FIRST (nothing else can hide their round trip right behind the barrier); the next
+        // tile's DMA pieces (the other buffer's last readers passed that barrier) and its lse / delta load follow one per MFMA pair
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0q[i] = rdk(sQ, 0, i); x0d[i] = rdk(sdO, 0, i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { y0q[i] = rdk(sQ, 0, 4 + i); y0d[i] = rdk(sdO, 0, 4 + i); }
+        tl = load_ld(q0 + 64);                            // unconditional (clamped address): a load inside a branch is waited for at the join
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; p0[r] = 0.f; }
+        FS2_PIN_ACC(); __builtin_amdgcn_sched_barrier(0);
+        // ---- A0a | fetch X1a | DMA pieces 0, 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0q[i], kf[i], s0, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0d[i], vf[i], p0, 0, 0, 0);
+            x1q[i] = rdk(sQ, 1, i); x1d[i] = rdk(sdO, 1, i);
+            if ((i & 1) && more) dma_piece(q0 + 64, buf ^ 1, i >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        FS2_STAMP(1);
+        // ---- A0b | fetch X1b | DMA pieces 2, 3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y0q[i], kf[4 + i], s0, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y0d[i], vf[4 + i], p0, 0, 0, 0);
+            y1q[i] = rdk(sQ, 1, 4 + i); y1d[i] = rdk(sdO, 1, 4 + i);
+            if ((i & 1) && more) dma_piece(q0 + 64, buf ^ 1, 2 + (i >> 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] = 0.f; p1[r] = 0.f; }
+        FS2_PIN_ACC(); __builtin_amdgcn_sched_barrier(0);
+        FS2_STAMP(2);
+        // ---- A1a | p, dS of block 0, queries 0-15 | fetch T0a
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1q[i], kf[i], s1, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1d[i], vf[i], p1, 0, 0, 0);
+        }
+        softmax8(s0, p0, sl, sd, 0, 0, pa0a, da0a);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { t0d[nb] = rdt(sdO, 0, nb); t0q[nb] = rdt(sQ, 0, nb); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { FS2_SGB(FS2_SG_MFMA, 1); FS2_SGB(FS2_SG_DSR, 2); FS2_SGB(FS2_SG_VALU, 6); FS2_SGB(FS2_SG_TRANS, 1); }
+        FS2_PIN_ACC(); __builtin_amdgcn_sched_barrier(0);
+        FS2_STAMP(3);
+        // ---- A1b | p, dS of block 0, queries 16-31 | fetch T0b
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y1q[i], kf[4 + i], s1, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y1d[i], vf[4 + i], p1, 0, 0, 0);
+        }
+        softmax8(s0, p0, sl, sd, 0, 1, pa0b, da0b);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { u0d[nb] = rdt(sdO, 16, nb); u0q[nb] = rdt(sQ, 16, nb); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { FS2_SGB(FS2_SG_MFMA, 1); FS2_SGB(FS2_SG_DSR, 2); FS2_SGB(FS2_SG_VALU, 6); FS2_SGB(FS2_SG_TRANS, 1); }
+        FS2_PIN_ACC(); __builtin_amdgcn_sched_barrier(0);
+        FS2_STAMP(4);
+        // ---- C0a | p, dS of block 1, queries 0-15 | fetch T1a
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0a, t0d[nb], dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0a, t0q[nb], dk[nb], 0, 0, 0);
+        }
+        softmax8(s1, p1, sl, sd, 1, 0, pa1a, da1a);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { t1d[nb] = rdt(sdO, 32, nb); t1q[nb] = rdt(sQ, 32, nb); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { FS2_SGB(FS2_SG_MFMA, 1); FS2_SGB(FS2_SG_DSR, 2); FS2_SGB(FS2_SG_VALU, 6); FS2_SGB(FS2_SG_TRANS, 1); }
+        FS2_PIN_ACC(); __builtin_amdgcn_sched_barrier(0);
+        FS2_STAMP(5);
+        // ---- C0b | p, dS of block 1, queries 16-31 | fetch T1b
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0b, u0d[nb], dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0b, u0q[nb], dk[nb], 0, 0, 0);
+        }
+        softmax8(s1, p1, sl, sd, 1, 1, pa1b, da1b);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { u1d[nb] = rdt(sdO, 48, nb); u1q[nb] = rdt(sQ, 48, nb); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { FS2_SGB(FS2_SG_MFMA, 1); FS2_SGB(FS2_SG_DSR, 2); FS2_SGB(FS2_SG_VALU, 6); FS2_SGB(FS2_SG_TRANS, 1); }
+        FS2_PIN_ACC(); __builtin_amdgcn_sched_barrier(0);
+        FS2_STAMP(6);
+        // ---- C1a, C1b
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1a, t1d[nb], dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1a, t1q[nb], dk[nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1b, u1d[nb], dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1b, u1q[nb], dk[nb], 0, 0, 0);
+        }
+        FS2_STAMP(7);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(tl) :: "memory");      // my pieces of the next tile and its lse / delta value have landed
+        FS2_STAMP(8);
+        if (tid < 128) sLD[buf ^ 1][tid >> 6][tid & 63] = conv_ld(tl, q0 + 64);       // (after the last tile: into a buffer nobody reads)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ak[i] += (unsigned)flip;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { at0[nb] += (unsigned)flip; at1[nb] += (unsigned)flip; }
+        flip = -flip;
+        FS2_PIN_ACC();
+        FS2_STAMP(9);
+        __syncthreads();
+        FS2_STAMP(10);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int key = kbase + crow(r, h2);
+        if (key < S) {
+            const float kz = key < len ? 1.f : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                dK[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dk[nb][r] * scale * kz);
+                dV[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dv[nb][r] * kz);
+            }
+        }
+    }
+}
+
 // (also computes delta[q] = sum_d dO[q][d] O[q][d] for its queries - a lane already holds half of its query's dO row - and
 // writes it for the dK/dV kernel, which therefore runs AFTER this one: the separate delta launch, 12 us per layer, is gone)
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
@@ -925,7 +1232,9 @@ extern "C" int fs2_attn_bwd(const void* qkv, const void* ctx, const void* dctx, 
     } else if (dtype == FS2_BF16) {
         // dQ first: it also produces delta (row sums of dO * O) for the dK/dV kernel
         attn_bwd_dq_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)ctx, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
-        attn_bwd_dkv_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
+        static const int dkv_form = fs2_dev_env("FS2_ATTN_DKV", 2);          // dev A/B: 1 = the phase-serial first form
+        if (dkv_form == 1) attn_bwd_dkv_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
+        else attn_bwd_dkv2_bf16_kernel<<<grid, 256, 0, stream>>>((const bf16_t*)qkv, ld, (const bf16_t*)dctx, ldo, lse, delta, (bf16_t*)dqkv, lens, S, H, scale);
     } else { fs2_set_error("attn_bwd: dtype"); return FS2_EDTYPE; }
     FS2_CHECK_LAUNCH("attn_bwd");
     return FS2_OK;
