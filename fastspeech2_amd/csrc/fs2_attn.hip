@@ -204,19 +204,114 @@ __device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* row, int
 // sequence's last row instead of zero-filled: every consumer already multiplies rows >= len by an exact 0 probability /
 // score gradient, so only finiteness matters, and the load needs no predicate (r01h: the synchronous
 // load -> ds_write -> barrier staging left the MFMA pipe idle for the whole L2 round trip of every tile).
+// (32-bit element offsets from the wave-uniform base: the 64-bit form cost ~6 vector instructions per load)
 #define TILE_LD1(t, base, ld_, row0, last_row, I) \
-    (t##I) = *reinterpret_cast<const uint4*>((base) + (size_t)min((row0) + ((tid + 256 * I) >> 4), (last_row)) * (ld_) + (tid & 15) * 8)
+    (t##I) = *reinterpret_cast<const uint4*>((base) + (unsigned)(min((row0) + ((tid + 256 * I) >> 4), (last_row)) * (int)(ld_) + (tid & 15) * 8))
 #define TILE_LOAD_REGS(t, base, ld_, row0, last_row) do { TILE_LD1(t, base, ld_, row0, last_row, 0); TILE_LD1(t, base, ld_, row0, last_row, 1); \
     TILE_LD1(t, base, ld_, row0, last_row, 2); TILE_LD1(t, base, ld_, row0, last_row, 3); } while (0)
 #define TILE_ST1(lds, t, I) *reinterpret_cast<uint4*>((lds) + swzb((tid + 256 * I) >> 4, tid & 15)) = (t##I)
 #define TILE_STORE_REGS(lds, t) do { TILE_ST1(lds, t, 0); TILE_ST1(lds, t, 1); TILE_ST1(lds, t, 2); TILE_ST1(lds, t, 3); } while (0)
 
+
+#ifdef FS2_DEV
+// dev builds: s_memtime stamps of workgroup (0, 0, 0), wave 0 at the phase boundaries of its first tiles (tools/attn_phases.py)
+__device__ unsigned long long fs2_attn_stamps[16 * 12];
+__device__ int fs2_attn_stamp_kernel = 2;      // 0 = forward, 1 = dQ, 2 = dK/dV (set with fs2_dev_attn_stamp_select)
+extern "C" int fs2_dev_attn_stamp_select(int k) { return hipMemcpyToSymbol(HIP_SYMBOL(fs2_attn_stamp_kernel), &k, sizeof(int)) == hipSuccess ? 0 : 1; }
+extern "C" int fs2_dev_attn_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs2_attn_stamps), sizeof(fs2_attn_stamps)) == hipSuccess ? 0 : 1;
+}
+// (the selector is read ONCE, at the top of the kernel: a load beside every stamp is a vmcnt(0) wait beside every stamp)
+#define FS2_STAMP_INIT() const bool fs2_stamp_on = fs2_attn_stamp_kernel == FS2_STAMP_KERNEL && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0
+#define FS2_STAMP_AT(t0_, i) do { if (fs2_stamp_on && (t0_) < 16 * 64) fs2_attn_stamps[((t0_) >> 6) * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FS2_STAMP(i) FS2_STAMP_AT(q0, i)
+#else
+#define FS2_STAMP_INIT() do {} while (0)
+#define FS2_STAMP_AT(t0_, i) do {} while (0)
+#define FS2_STAMP(i) do {} while (0)
+#endif
+
+// XCD-AWARE BLOCK MAP (round 6).  The grid is (tiles, H, B) and the dispatcher deals consecutive workgroups round-robin to the 8
+// XCDs - with the tile index fastest, the 8 query (key) tiles of ONE (sequence, head) landed on 8 different XCDs and each of them
+// pulled that head's whole K / V (Q / dO) stream through its own L2: 8 x the fabric traffic (r05zzz PMC: 143-167 MB fetched per
+// decoder launch for ~91 MB of operands; r06p phase stamps: the forward's 8 tile loads alone held a wave for 1 300 - 2 500 cycles of a
+// 5 400-cycle tile).  Here the dispatch-order index L is re-read as: groups of 8 (sequence, head) pairs, inside a group the PAIR is
+// the fastest index (L mod 8 = the XCD) and the tile the slower one - the tiles of a pair share an XCD and start together.
+__device__ __forceinline__ void attn_block_map(int H, int& t, int& h, int& b) {
+    const int nt = (int)gridDim.x, nbh = (int)(gridDim.y * gridDim.z);
+    const int L = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    const int G = L / (8 * nt), r = L - G * (8 * nt);
+    const int rem = min(8, nbh - 8 * G);                    // pairs in this group (< 8 only in the last one)
+    const int bh = 8 * G + r % rem;
+    t = r / rem;
+    b = bh / H; h = bh - b * H;
+}
+
+// Lane-constant fragment addresses of a [64 rows][256 B] swizzled tile image pair (round 6): absolute LDS byte addresses of this
+// lane's pieces in the CURRENT buffer's first image; the second image (+16 KiB), the 32-row block (+8 KiB) and the 16-row group of a
+// transposing read (+4 KiB) enter as immediate offsets, and flip() moves all of them to the other buffer (+-32 KiB) once per tile.
+// The first form recomputed swzb() for every read: ~80 of a tile's ~240 vector instructions in the forward kernel.
+struct FragAddr {
+    unsigned k[8], t0[4], t1[4], st[4];
+    int step;
+    __device__ __forceinline__ void init(unsigned base, int tid) {
+        const int lane = tid & 63, fl = lane & 31, h2 = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] = base + (unsigned)swzb(fl, 2 * i + h2);
+        const int li = lane & 15, g = lane >> 4, hh = g >> 1, rr = 4 * hh + (li >> 2);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int col = nb * 32 + 16 * (g & 1) + 4 * (li & 3);
+            t0[nb] = base + (unsigned)(swzb(rr, col >> 3) + ((col & 7) << 1));
+            t1[nb] = base + (unsigned)(swzb(rr + 8, col >> 3) + ((col & 7) << 1));
+        }
+#pragma unroll
+        for (int I = 0; I < 4; ++I) st[I] = base + 32768u + (unsigned)swzb((tid + 256 * I) >> 4, tid & 15);   // stores go to the OTHER buffer
+        step = 32768;
+    }
+    __device__ __forceinline__ void flip() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k[i] += (unsigned)step;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { t0[nb] += (unsigned)step; t1[nb] += (unsigned)step; }
+#pragma unroll
+        for (int I = 0; I < 4; ++I) st[I] -= (unsigned)step;
+        step = -step;
+    }
+    // K-contiguous fragment: image img (0 / 1), 32-row block blk, d-slice i
+    __device__ __forceinline__ bf16x8 rk(int img, int blk, int i) const {
+        typedef unsigned lds_v4u __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const lds_v4u* lds_u4p;
+        return __builtin_bit_cast(bf16x8, *(lds_u4p)(size_t)(k[i] + (unsigned)(img * 16384 + blk * 8192)));
+    }
+    // transposed fragment: image img, rows rb .. rb + 15 (rb a multiple of 16), column block nb
+    __device__ __forceinline__ bf16x8 rt(int img, int rb, int nb) const {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(t0[nb] + (unsigned)(img * 16384 + rb * 256)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(t1[nb] + (unsigned)(img * 16384 + rb * 256)));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+    // register-staged tile store into the other buffer's image img
+    __device__ __forceinline__ void store(int img, const uint4& v, int I) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned lds_v4u __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) lds_v4u* lds_u4w;
+        *(lds_u4w)(size_t)(st[I] + (unsigned)(img * 16384)) = lds_v4u{v.x, v.y, v.z, v.w};
+#else
+        (void)img; (void)v; (void)I;
+#endif
+    }
+};
+#define TILE_STORE_FA(fa, img, t) do { (fa).store(img, t##0, 0); (fa).store(img, t##1, 1); (fa).store(img, t##2, 2); (fa).store(img, t##3, 3); } while (0)
+
+#define FS2_STAMP_KERNEL 0
 __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
                                                                long ldo, float* __restrict__ lse,
                                                                const int32_t* __restrict__ lens, int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
+    FS2_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qt, h, b;
+    attn_block_map(H, qt, h, b);
     const int len = lens ? min(lens[b], S) : S;
     const int q0 = qt * 128;
     const size_t rowbase = (size_t)b * S;
@@ -250,29 +345,30 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
     TILE_STORE_REGS(sKV[0][0], tk);
     TILE_STORE_REGS(sKV[0][1], tv);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
+    FragAddr fa;
+    fa.init(lds_addr(&sKV[0][0][0]), tid);
+    for (int k0 = 0; k0 < len; k0 += 64) {
         const bool more = k0 + 64 < len;
+        FS2_STAMP_AT(k0, 0);
         if (more) {                                       // next tile travels while this one is multiplied
             TILE_LOAD_REGS(tk, K, ld, k0 + 64, S - 1);
             TILE_LOAD_REGS(tv, V, ld, k0 + 64, S - 1);
         }
-        const unsigned char* sK = sKV[buf][0];
-        const unsigned char* sV = sKV[buf][1];
         // software pipeline over the 8 d-slices: the two K fragments of slice st+1 are in flight while slice st is
         // multiplied (two independent accumulator chains); sched_barrier pins the order - unpinned, the scheduler sinks
         // each read to just above its MFMA (r01i ISA: ds_read / s_waitcnt lgkmcnt(0) / v_mfma, 16 times in a row)
+        FS2_STAMP_AT(k0, 1);
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         {
-            bf16x8 c0 = frag_k(sK, fl, 0, h2), c1 = frag_k(sK, 32 + fl, 0, h2);
+            bf16x8 c0 = fa.rk(0, 0, 0), c1 = fa.rk(0, 1, 0);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 bf16x8 n0 = c0, n1 = c1;
-                if (st < 7) { n0 = frag_k(sK, fl, st + 1, h2); n1 = frag_k(sK, 32 + fl, st + 1, h2); }
+                if (st < 7) { n0 = fa.rk(0, 0, st + 1); n1 = fa.rk(0, 1, st + 1); }
                 __builtin_amdgcn_sched_barrier(0);
                 s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, qf[st], s[0], 0, 0, 0);
                 s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, qf[st], s[1], 0, 0, 0);
@@ -285,6 +381,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
         // when some query's maximum grew by more than 2^8 - after the first tiles that is almost never, and a rescale costs
         // 16 cross-lane permutes + 64 multiplies per wave and tile (r02s PMC: 15.7 VALU instructions per MFMA made this kernel
         // VALU-bound 2:1).  A stale maximum only scales p and l by the same factor <= 2^8: o / l is unchanged.
+        FS2_STAMP_AT(k0, 2);
         if (k0 + 64 > len) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -317,15 +414,16 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
             for (int r = 0; r < 16; ++r) { s[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc2, -m)); rs += s[kb][r]; }
         rs += __shfl_xor(rs, 32, 64);
         l += rs;
+        FS2_STAMP_AT(k0, 3);
         {   // P V: the four V fragments of the next 16-key group are fetched while the current group is multiplied
             bf16x8 cv[4], nv[4];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) cv[nb] = frag_t(sV, 0, nb, lane);
+            for (int nb = 0; nb < 4; ++nb) cv[nb] = fa.rt(1, 0, nb);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                 // g = 2*kb + u: keys 16g .. 16g+15 of the tile
                 if (g < 3) {
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) nv[nb] = frag_t(sV, 16 * (g + 1), nb, lane);
+                    for (int nb = 0; nb < 4; ++nb) nv[nb] = fa.rt(1, 16 * (g + 1), nb);
                 }
                 float pv[8];
 #pragma unroll
@@ -339,11 +437,15 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
                 for (int nb = 0; nb < 4; ++nb) cv[nb] = nv[nb];
             }
         }
+        FS2_STAMP_AT(k0, 4);
         if (more) {
-            TILE_STORE_REGS(sKV[buf ^ 1][0], tk);
-            TILE_STORE_REGS(sKV[buf ^ 1][1], tv);
+            TILE_STORE_FA(fa, 0, tk);
+            TILE_STORE_FA(fa, 1, tv);
         }
+        fa.flip();
+        FS2_STAMP_AT(k0, 5);
         __syncthreads();
+        FS2_STAMP_AT(k0, 6);
     }
     float linv = l > 0.f ? 1.f / l : 0.f;
     if (h2 == 0 && myq < S) lse_o[myq] = (l > 0.f) ? m * 0.6931471805599453f + __logf(l) : 0.f;      // natural-log lse for the backward
@@ -358,6 +460,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
     }
 }
 
+#undef FS2_STAMP_KERNEL
 // dK, dV: one wave owns 32 keys (K, V fragments in registers); the block streams 64-query tiles of Q / dO.
 // Per tile the log-sum-exp and delta values of its 64 queries travel with the Q / dO prefetch into LDS: the first
 // version fetched them from GLOBAL memory element by element inside the `key_ok && q < len` branch - 32 dependent,
@@ -548,16 +651,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv_bf16_kernel(const bf16_t*
 #define FS2_SG_TRANS 0x400
 #define FS2_SG_DSR 0x100
 #define FS2_SG_DSW 0x200
-#ifdef FS2_DEV
-// dev builds: s_memtime stamps of workgroup (0, 0, 0), wave 0 at the phase boundaries of its first tiles (tools/attn_phases.py)
-__device__ unsigned long long fs2_attn_stamps[16 * 12];
-extern "C" int fs2_dev_attn_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs2_attn_stamps), sizeof(fs2_attn_stamps)) == hipSuccess ? 0 : 1;
-}
-#define FS2_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && q0 < 16 * 64) fs2_attn_stamps[(q0 >> 6) * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FS2_STAMP(i) do {} while (0)
-#endif
+#define FS2_STAMP_KERNEL 2
 __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                                     const bf16_t* __restrict__ dctx, long ldo,
                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
@@ -565,8 +659,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t
                                                                     int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sQD[2][2][64 * 256];   // [buffer][Q | dO]
     __shared__ __attribute__((aligned(16))) float sLD[2][2][64];                 // [buffer][lse | delta] of the tile's queries
+    FS2_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
-    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int kt, h, b;
+    attn_block_map(H, kt, h, b);
     const int len = lens ? min(lens[b], S) : S;
     const size_t rowbase = (size_t)b * S;
     const int kbase = kt * 128 + w * 32;
@@ -836,6 +932,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t
     }
 }
 
+#undef FS2_STAMP_KERNEL
 // (also computes delta[q] = sum_d dO[q][d] O[q][d] for its queries - a lane already holds half of its query's dO row - and
 // writes it for the dK/dV kernel, which therefore runs AFTER this one: the separate delta launch, 12 us per layer, is gone)
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
@@ -846,7 +943,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                                                                   int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qt, h, b;
+    attn_block_map(H, qt, h, b);
     const int len = lens ? min(lens[b], S) : S;
     const int q0 = qt * 128;
     const size_t rowbase = (size_t)b * S;
@@ -902,15 +1000,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
     TILE_STORE_REGS(sKV[0][0], tk);
     TILE_STORE_REGS(sKV[0][1], tv);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
+    FragAddr fa;
+    fa.init(lds_addr(&sKV[0][0][0]), tid);
+    for (int k0 = 0; k0 < len; k0 += 64) {
         const bool more = k0 + 64 < len;
         if (more) {
             TILE_LOAD_REGS(tk, K, ld, k0 + 64, S - 1);
             TILE_LOAD_REGS(tv, V, ld, k0 + 64, S - 1);
         }
-        const unsigned char* sK = sKV[buf][0];
-        const unsigned char* sV = sKV[buf][1];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (k0 + kb * 32 >= len) break;
@@ -920,11 +1017,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
             {
-                bf16x8 ck = frag_k(sK, kb * 32 + fl, 0, h2), cv = frag_k(sV, kb * 32 + fl, 0, h2);
+                bf16x8 ck = fa.rk(0, kb, 0), cv = fa.rk(1, kb, 0);
 #pragma unroll
                 for (int st = 0; st < 8; ++st) {
                     bf16x8 nk = ck, nv = cv;
-                    if (st < 7) { nk = frag_k(sK, kb * 32 + fl, st + 1, h2); nv = frag_k(sV, kb * 32 + fl, st + 1, h2); }
+                    if (st < 7) { nk = fa.rk(0, kb, st + 1); nv = fa.rk(1, kb, st + 1); }
                     __builtin_amdgcn_sched_barrier(0);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ck, qf[st], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cv, df[st], dp, 0, 0, 0);
@@ -952,13 +1049,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 bf16x8 da = pack8(dsv + 8 * u);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_t(sK, kb * 32 + 16 * u, nb, lane), dq[nb], 0, 0, 0);
+                    dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, fa.rt(0, kb * 32 + 16 * u, nb), dq[nb], 0, 0, 0);
             }
         }
         if (more) {
-            TILE_STORE_REGS(sKV[buf ^ 1][0], tk);
-            TILE_STORE_REGS(sKV[buf ^ 1][1], tv);
+            TILE_STORE_FA(fa, 0, tk);
+            TILE_STORE_FA(fa, 1, tv);
         }
+        fa.flip();
         __syncthreads();
     }
 #pragma unroll

@@ -15,12 +15,23 @@ lens = torch.as_tensor(b["mel_lens"]).to(torch.int32).to(dev)
 qkv = (torch.randn(B * S, 3 * H * 128, device=dev) * 0.5).to(torch.bfloat16)
 dctx = torch.randn(B * S, H * 128, device=dev).to(torch.bfloat16)
 ctx, lse = ops.attn_fwd(qkv, lens, B, S, H)
+lib = ctypes.CDLL(os.environ["FS2_LIB_PATH"])
+which = int(sys.argv[1]) if len(sys.argv) > 1 else 2          # 0 = forward, 2 = dK/dV
+assert lib.fs2_dev_attn_stamp_select(which) == 0
 for _ in range(3):
+    ops.attn_fwd(qkv, lens, B, S, H)
     ops.attn_bwd(qkv, ctx, dctx, lse, lens, B, S, H)
 torch.cuda.synchronize()
-lib = ctypes.CDLL(os.environ["FS2_LIB_PATH"])
 buf = (ctypes.c_ulonglong * (16 * 12))()
 assert lib.fs2_dev_attn_stamps(buf) == 0
+if which == 0:
+    names = ["prefetch issue", "QK^T", "softmax", "PV", "store", "barrier"]
+    print("tile " + " ".join(f"{n:>14s}" for n in names) + "       total")
+    for t in range(1, 12):
+        st = [buf[t * 12 + i] for i in range(7)]
+        if st[6] == 0: break
+        print(f"{t:4d} " + " ".join(f"{st[i + 1] - st[i]:14d}" for i in range(6)) + f" {st[6] - st[0]:11d}")
+    sys.exit(0)
 names = ["reads+A0a", "A0b", "A1a|B0'", "A1b|B0\"", "C0a|B1'", "C0b|B1\"", "C1", "vmcnt wait", "store+flip", "barrier"]
 print("tile " + " ".join(f"{n:>11s}" for n in names) + "       total")
 for t in range(1, 12):
