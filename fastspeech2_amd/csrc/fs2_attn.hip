@@ -303,6 +303,34 @@ struct FragAddr {
 };
 #define TILE_STORE_FA(fa, img, t) do { (fa).store(img, t##0, 0); (fa).store(img, t##1, 1); (fa).store(img, t##2, 2); (fa).store(img, t##3, 3); } while (0)
 
+
+// Row-per-lane epilogue (round 6).  The P V / dS K / P^T dO products are issued with their operands SWAPPED, so the accumulators hold
+// the TRANSPOSED result: lane = output ROW (query / key), registers = columns d = 32 nb + 8 (r >> 2) + 4 h2 + (r & 3).  One
+// v_permlane32_swap per register pair then gives each half-wave 8 consecutive columns = one 16-byte bf16 store (8 per lane instead
+// of the 64 two-byte stores of the column-per-lane form - a store-issue-bound tail of the order of a tenth of a workgroup's life),
+// and every per-row factor (the online-softmax rescale, 1 / l, the softmax scale) is a per-LANE scalar: no cross-lane shuffles.
+typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void attn_store_row(bf16_t* rowp, const f32x16 (&acc)[4], float f, int h2, bool ok) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        float c[2][8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            attn_u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[nb][e]), __float_as_uint(acc[nb][4 + e]), false, false);
+            attn_u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[nb][8 + e]), __float_as_uint(acc[nb][12 + e]), false, false);
+            c[0][e] = __uint_as_float(s0[0]); c[0][4 + e] = __uint_as_float(s0[1]);
+            c[1][e] = __uint_as_float(s1[0]); c[1][4 + e] = __uint_as_float(s1[1]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            uint4 o;
+            o.x = pack_bf16x2(c[ch][0] * f, c[ch][1] * f); o.y = pack_bf16x2(c[ch][2] * f, c[ch][3] * f);
+            o.z = pack_bf16x2(c[ch][4] * f, c[ch][5] * f); o.w = pack_bf16x2(c[ch][6] * f, c[ch][7] * f);
+            if (ok) *reinterpret_cast<uint4*>(rowp + nb * 32 + ch * 16 + h2 * 8) = o;
+        }
+    }
+}
+
 #define FS2_STAMP_KERNEL 0
 __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
                                                                long ldo, float* __restrict__ lse,
@@ -401,10 +429,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
             l *= alpha;
             m = mn;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float ar = __shfl(alpha, crow(r, h2), 64);
+            for (int r = 0; r < 16; ++r) {               // (transposed accumulators: lane = query, so alpha is this lane's own)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
+                for (int nb = 0; nb < 4; ++nb) o[nb][r] *= alpha;
             }
         }
         float rs = 0.f;
@@ -431,7 +458,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
                 bf16x8 pa = pack8(pv);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, cv[nb], o[nb], 0, 0, 0);
+                for (int nb = 0; nb < 4; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cv[nb], pa, o[nb], 0, 0, 0);     // O^T[d][q] += V^T P^T
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) cv[nb] = nv[nb];
@@ -449,17 +476,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
     }
     float linv = l > 0.f ? 1.f / l : 0.f;
     if (h2 == 0 && myq < S) lse_o[myq] = (l > 0.f) ? m * 0.6931471805599453f + __logf(l) : 0.f;      // natural-log lse for the backward
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float li = __shfl(linv, crow(r, h2), 64);
-        int q = q0 + w * 32 + crow(r, h2);
-        if (q < S) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) out[(size_t)q * ldo + nb * 32 + fl] = f32_to_bf16(o[nb][r] * li);
-        }
-    }
+    attn_store_row(out + (size_t)min(myq, S - 1) * ldo, o, linv, h2, myq < S);
 }
-
 #undef FS2_STAMP_KERNEL
 // dK, dV: one wave owns 32 keys (K, V fragments in registers); the block streams 64-query tiles of Q / dO.
 // Per tile the log-sum-exp and delta values of its 64 queries travel with the Q / dO prefetch into LDS: the first
@@ -870,8 +888,8 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t
         // ---- C0a | p, dS of block 1, queries 0-15 | fetch T1a
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0a, t0d[nb], dv[nb], 0, 0, 0);
-            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0a, t0q[nb], dk[nb], 0, 0, 0);
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t0d[nb], pa0a, dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t0q[nb], da0a, dk[nb], 0, 0, 0);
         }
         softmax8(s1, p1, sl, sd, 1, 0, pa1a, da1a);
 #pragma unroll
@@ -883,8 +901,8 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t
         // ---- C0b | p, dS of block 1, queries 16-31 | fetch T1b
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0b, u0d[nb], dv[nb], 0, 0, 0);
-            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0b, u0q[nb], dk[nb], 0, 0, 0);
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u0d[nb], pa0b, dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u0q[nb], da0b, dk[nb], 0, 0, 0);
         }
         softmax8(s1, p1, sl, sd, 1, 1, pa1b, da1b);
 #pragma unroll
@@ -896,13 +914,13 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t
         // ---- C1a, C1b
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1a, t1d[nb], dv[nb], 0, 0, 0);
-            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1a, t1q[nb], dk[nb], 0, 0, 0);
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t1d[nb], pa1a, dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t1q[nb], da1a, dk[nb], 0, 0, 0);
         }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1b, u1d[nb], dv[nb], 0, 0, 0);
-            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1b, u1q[nb], dk[nb], 0, 0, 0);
+            dv[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1d[nb], pa1b, dv[nb], 0, 0, 0);
+            dk[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1q[nb], da1b, dk[nb], 0, 0, 0);
         }
         FS2_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(tl) :: "memory");      // my pieces of the next tile and its lse / delta value have landed
@@ -918,20 +936,13 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t
         __syncthreads();
         FS2_STAMP(10);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int key = kbase + crow(r, h2);
-        if (key < S) {
-            const float kz = key < len ? 1.f : 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                dK[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dk[nb][r] * scale * kz);
-                dV[(size_t)key * ld + nb * 32 + fl] = f32_to_bf16(dv[nb][r] * kz);
-            }
-        }
+    // (transposed accumulators dK^T / dV^T [d][key]: lane = key)
+    {
+        const float kz = mykey < len ? 1.f : 0.f;           // a padded key's rows come out as zeros
+        attn_store_row(dK + (size_t)min(mykey, S - 1) * ld, dk, scale * kz, h2, mykey < S);
+        attn_store_row(dV + (size_t)min(mykey, S - 1) * ld, dv, kz, h2, mykey < S);
     }
 }
-
 #undef FS2_STAMP_KERNEL
 // (also computes delta[q] = sum_d dO[q][d] O[q][d] for its queries - a lane already holds half of its query's dO row - and
 // writes it for the dK/dV kernel, which therefore runs AFTER this one: the separate delta launch, 12 us per layer, is gone)
@@ -1049,7 +1060,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 bf16x8 da = pack8(dsv + 8 * u);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, fa.rt(0, kb * 32 + 16 * u, nb), dq[nb], 0, 0, 0);
+                    dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rt(0, kb * 32 + 16 * u, nb), da, dq[nb], 0, 0, 0);       // dQ^T[d][q] += K^T dS^T
             }
         }
         if (more) {
@@ -1059,14 +1070,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
         fa.flip();
         __syncthreads();
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int q = q0 + w * 32 + crow(r, h2);
-        if (q < S) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) dQ[(size_t)q * ld + nb * 32 + fl] = f32_to_bf16(dq[nb][r] * scale);
-        }
-    }
+    attn_store_row(dQ + (size_t)min(myq, S - 1) * ld, dq, scale, h2, myq < S);
 }
 
 extern "C" int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_t* lens, int B, int S, int H, int dk,
