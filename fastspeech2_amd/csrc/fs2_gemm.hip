@@ -974,7 +974,8 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, b
     GemmPick p;
     const long grid = (long)fs2_cdiv(M, 128) * fs2_cdiv(N, 128);
     // taps == 1 keeps the register-staged kernel (its 3-stage pipeline wins when there is no halo to reuse)
-    const bool dma = in_act == FS2_ACT_NONE && taps > 1 && (taps - 1) * dil <= 16 && taps <= 32;
+    static const int dma1 = fs2_dev_env("FS2_GEMM_DMA1", 1);            // dev A/B: one-tap launches of few tiles and K >= 768 on the DMA kernel's in-workgroup K split
+    const bool dma = in_act == FS2_ACT_NONE && (taps > 1 || (dma1 && grid <= 160 && Cin % 128 == 0 && Cin >= 768 && dtype == FS2_BF16)) && (taps - 1) * dil <= 16 && taps <= 32;
     // ring-buffered 256x128 tiles once there are enough of them to fill the chip (FS2_GEMM_TILE=128|256: dev A/B only)
     static const int force_tile = fs2_dev_env("FS2_GEMM_TILE", 0);
     const long big_tiles = (long)fs2_cdiv(M, 256) * fs2_cdiv(N, 128);
@@ -1004,7 +1005,8 @@ static GemmPick conv_gemm_pick(const ConvGemmArgs& a, int dtype, bool has_map, b
     const bool persist = p_on && !skinny && !res_short && fs2_conv_gemm_p_ok(a, has_map, dtype, 1) && (taps > 1 || Cin >= 256);
     // few tiles, long reduction: split the Cin chunks over two wave groups of one workgroup (FS2_GEMM_KSPLIT=0: off)
     static const int ksplit_on = fs2_dev_env("FS2_GEMM_KSPLIT", 1);
-    p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= 32;
+    static const int ks2_min = fs2_dev_env("FS2_GEMM_KS2_MIN", 12);
+    p.ks2 = ksplit_on && dtype == FS2_BF16 && grid <= 160 && Cin % 128 == 0 && (long)taps * (Cin / 64) >= ks2_min;
     // wide-tile one-tap kernel (fs2_gemm_w.hip): N a multiple of 256 - the Linear layers of the FFT blocks and their data gradients
     static const int w_on = fs2_dev_env("FS2_GEMM_W", 1);
     // streaming kernel with the weights in registers (fs2_gemm_s.hip): the K = 256 Linear layers and data gradients
