@@ -331,11 +331,24 @@ __device__ __forceinline__ void attn_store_row(bf16_t* rowp, const f32x16 (&acc)
     }
 }
 
+// Raised wave priority around the MFMA runs of the two-waves-per-SIMD kernels (MI355X_MICROARCH: +4-7 % on an attention loop; here the
+// forward 60.6 -> 58.8 us same process, tools/attn_prio.py): the wave that is in a matrix run is not held up by its partner's softmax VALU.
+// Dev builds can switch it off (fs2_dev_attn_prio).
+#ifdef FS2_DEV
+__device__ int fs2_attn_prio_on = 1;
+extern "C" int fs2_dev_attn_prio(int on) { return hipMemcpyToSymbol(HIP_SYMBOL(fs2_attn_prio_on), &on, sizeof(int)) == hipSuccess ? 0 : 1; }
+#define FS2_ATTN_PRIO_INIT() const bool fs2_prio = fs2_attn_prio_on != 0
+#define FS2_ATTN_PRIO(v) do { if (fs2_prio) { if (v) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
+#else
+#define FS2_ATTN_PRIO_INIT() do {} while (0)
+#define FS2_ATTN_PRIO(v) __builtin_amdgcn_s_setprio(v)
+#endif
 #define FS2_STAMP_KERNEL 0
 __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, long ld, bf16_t* __restrict__ ctx,
                                                                long ldo, float* __restrict__ lse,
                                                                const int32_t* __restrict__ lens, int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
+    FS2_ATTN_PRIO_INIT();
     FS2_STAMP_INIT();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
     int qt, h, b;
@@ -392,6 +405,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         {
+            FS2_ATTN_PRIO(1);
             bf16x8 c0 = fa.rk(0, 0, 0), c1 = fa.rk(0, 1, 0);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
@@ -403,6 +417,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
                 __builtin_amdgcn_sched_barrier(0);
                 c0 = n0; c1 = n1;
             }
+            FS2_ATTN_PRIO(0);
         }
         // Softmax bookkeeping in the log2 domain (p = exp2(s * scale * log2 e - m): one fma + one v_exp_f32 per score), the
         // key-padding mask only on the sequence's last tile, and a LAZY running maximum: the accumulators are rescaled only
@@ -444,6 +459,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
         FS2_STAMP_AT(k0, 3);
         {   // P V: the four V fragments of the next 16-key group are fetched while the current group is multiplied
             bf16x8 cv[4], nv[4];
+            FS2_ATTN_PRIO(1);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) cv[nb] = fa.rt(1, 0, nb);
 #pragma unroll
@@ -463,6 +479,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) cv[nb] = nv[nb];
             }
+            FS2_ATTN_PRIO(0);
         }
         FS2_STAMP_AT(k0, 4);
         if (more) {
@@ -953,6 +970,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                                                                   bf16_t* __restrict__ dqkv, const int32_t* __restrict__ lens,
                                                                   int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
+    FS2_ATTN_PRIO_INIT();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
     int qt, h, b;
     attn_block_map(H, qt, h, b);
@@ -1028,6 +1046,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
             {
+                FS2_ATTN_PRIO(1);
                 bf16x8 ck = fa.rk(0, kb, 0), cv = fa.rk(1, kb, 0);
 #pragma unroll
                 for (int st = 0; st < 8; ++st) {
@@ -1039,6 +1058,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                     __builtin_amdgcn_sched_barrier(0);
                     ck = nk; cv = nv;
                 }
+                FS2_ATTN_PRIO(0);
             }
             float dsv[16];
             // the only key block with padded keys gets its scores masked BEFORE the exponential, behind a wave-uniform branch (as a
@@ -1055,6 +1075,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -my_lse2));
                 dsv[r] = p * (dp[r] - my_del);                                  // (the softmax scale multiplies dQ once, at the store)
             }
+            FS2_ATTN_PRIO(1);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 bf16x8 da = pack8(dsv + 8 * u);
@@ -1062,6 +1083,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 for (int nb = 0; nb < 4; ++nb)
                     dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rt(0, kb * 32 + 16 * u, nb), da, dq[nb], 0, 0, 0);       // dQ^T[d][q] += K^T dS^T
             }
+            FS2_ATTN_PRIO(0);
         }
         if (more) {
             TILE_STORE_FA(fa, 0, tk);
