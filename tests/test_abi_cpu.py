@@ -74,3 +74,20 @@ def test_dispatch_queries_are_pure_host_functions():
         assert lib.fs2_conv_gemm_lrelu_io_variant(C, C, 0, 0, M, C, C, S, k, 1, 0, 0.0, 0.1, BF16) == 5
     assert lib.fs2_conv_gemm_variant(256, 1024, 0, 0, 0, 48 * 925, 1024, 256, 925, 9, 1, 0, 0.0, BF16) == 5
     assert lib.fs2_conv_gemm_variant(256, 768, 0, 0, 0, 48 * 925, 768, 256, 925, 1, 1, 0, 0.0, BF16) == 9
+
+
+def test_no_copy_of_an_in_flight_fragment_register_in_the_persistent_kernel():
+    """The persistent contraction kernel tracks its LDS fragment reads by hand (inline-asm ds_read_b128 + counted lgkmcnt); the
+    compiler does not know that such a register may still be in flight, so a register-to-register copy of one between its read and
+    the wait that lands it carries stale data (round 6: the eight-consumer-wave form came out 1 % wrong, timing-dependent, when its
+    K loop was two nested loops).  tools/check_frag_copies.py compiles the kernel to ISA and lists such copies: there must be none."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) and not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_frag_copies.py"), os.path.join(ROOT, "fastspeech2_amd", "csrc", "fs2_gemm_p.hip")],
+                       capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "conv_gemm_p_kernel<false, false, 0, 8>" in r.stdout and "conv_gemm_p_kernel<false, false, 0, 4>" in r.stdout
