@@ -40,21 +40,27 @@ def main():
             out = model(*batch[2:])
             return utils.synth_samples(batch, out, voc, mcfg, pcfg, None, write=False)
 
-    for i in range(6):
-        step(i)
+    pipe = utils.SynthPipeline(model, voc, (pcfg, mcfg), device=dev, voc_streams=3) if len(sys.argv) > 1 and sys.argv[1] == "pipe" else None
+    def run(n):
+        if pipe is None:
+            for i in range(n):
+                step(i)
+        else:
+            for _ in pipe(batches[i % len(batches)] for i in range(n)):
+                pass
+    run(6)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-        for i in range(3):
-            step(i)
+        run(3)
         torch.cuda.synchronize()
     by = collections.Counter()
     for e in prof.events():
         n = e.name
         if any(s in n for s in ("Memcpy", "memcpy", "copy_", "aten::to", "aten::item", "aten::_local_scalar_dense", "aten::mul", "aten::add",
-                                "aten::contiguous", "aten::clone", "aten::empty_like", "aten::cat", "aten::fill_")):
+                                "aten::contiguous", "aten::clone", "aten::cat", "aten::fill_", "hipMemcpy", "hipMemset", "Memset")):
             st = [f for f in (e.stack or []) if "fastspeech2_amd" in f or "bench.py" in f or "prof_synth" in f]
-            by[(n, st[0] if st else "?")] += 1
+            by[(n, (st[0] if st else "?")[-90:])] += 1
     for (n, st), c in by.most_common(40):
         print(f"{c / 3:7.1f} /step  {n:38s} {st}")
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
