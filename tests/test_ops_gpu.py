@@ -162,12 +162,13 @@ def attn_ref(qkv, lens, B, S, H):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("B,S,H", [(2, 100, 2), (3, 257, 2), (1, 31, 1), (2, 640, 2)])
+# (10, 200, 2) / (5, 130, 2): 20 / 10 (sequence, head) pairs = full groups of 8 AND a shorter last group in the XCD-aware block map
+@pytest.mark.parametrize("B,S,H", [(2, 100, 2), (3, 257, 2), (1, 31, 1), (2, 640, 2), (10, 200, 2), (5, 130, 2)])
 def test_attention(dev, dtype, tol, B, S, H):
     ops = _ops()
     torch.manual_seed(2)
     qkv = torch.randn(B * S, 3 * H * 128)
-    lens = torch.tensor([S - 13 * i for i in range(B)], dtype=torch.int32)
+    lens = torch.tensor([max(S - 13 * i, 7) for i in range(B)], dtype=torch.int32)
     qd = qkv.to(dev).to(dtype)
     qr = qd.float().cpu().double().requires_grad_(True)
     ref = attn_ref(qr, lens, B, S, H)
