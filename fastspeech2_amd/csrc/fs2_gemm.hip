@@ -1748,6 +1748,14 @@ static int conv_wgrad_impl(const void* dY, long lddy, const void* X, long ldx, f
                 WgradPlan p1 = {};
                 p1.g_first = 1; p1.n_first = 1; p1.n_rest = 0; p1.share = 1;
                 p1.tiles = fs2_cdiv(N, 128) * fs2_cdiv(Cin, 128);
+                // 128 (n) x 256 (c) tiles (round 6: a dY tile fetched once per 256 columns of X, a wave's two X runs against the same two dY
+                // fragments - 2 LDS instructions per MFMA instead of 3; three 48 KiB ring buffers).  Same box, profiles/r06x_bench_wgrad_wide.log:
+                // decoder w_2 (Cin = 1024) 69.6 -> 55.5 us, decoder QKV (N = 768) 53.4 -> 48.3; with few tiles it LOSES (decoder fc, 2 wide
+                // tiles: 24.5 -> 29.4; every encoder shape + 2.6 - 4.3 us): only launches with >= 6 wide tiles and a long row stream take it.
+                // FS2_WGRAD_TG1_WIDE (dev builds): 0 = never, 2 = whenever Cin % 256 == 0.
+                static const int one_wide = fs2_dev_env("FS2_WGRAD_TG1_WIDE", 1);
+                const long wide_tiles = (long)fs2_cdiv(N, 128) * (Cin / 256);
+                if (Cin % 256 == 0 && (one_wide == 2 || (one_wide == 1 && M >= 16384 && wide_tiles >= 6))) { p1.share = 2; p1.tiles = (int)wide_tiles; }
                 p1.units = (M / S_eff) * ((S_eff + 63) / 64);
                 long want = p1.tiles >= one_wgs ? 1 : (one_wgs + p1.tiles / 2) / p1.tiles;
                 const long max_by_units = p1.units / 8 > 0 ? p1.units / 8 : 1;

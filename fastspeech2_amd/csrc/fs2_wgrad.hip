@@ -40,12 +40,16 @@ typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int TG_A_BYTES = 64 * 256;              // dY tile: 64 rows x 128 n (bf16)
 // X tile: 64 rows (+ halo of NT - 1 <= 4 rows, rounded up to whole 4-row DMA pieces: 72) x 128 c
-template <int NT> struct TgCfg {
+// CB (one-tap launches only): 128-column X images per workgroup tile.  CB = 2 is the 128 (n) x 256 (c) tile of round 6: a wave owns
+// 64 x (32 + 32) outputs - two X runs against the same two dY fragments (2 LDS instructions per MFMA instead of 3) - and a dY tile is
+// fetched once per 256 columns of X instead of once per 128
+template <int NT, int CB = 1> struct TgCfg {
     static constexpr int X_ROWS = NT == 1 ? 64 : 72;
-    static constexpr int BUF_BYTES = TG_A_BYTES + X_ROWS * 256;
+    static constexpr int X_BYTES = X_ROWS * 256;
+    static constexpr int BUF_BYTES = TG_A_BYTES + CB * X_ROWS * 256;
     // ring depth: tile i is fetched NBUF - 1 tiles ahead.  One-tap launches are HBM-bound (a 32 KiB tile feeds 16 MFMAs per
     // wave): FOUR 32 KiB buffers keep three tiles in flight per CU (the register-staged kernel held two and moved 1.6 TB/s)
-    static constexpr int NBUF = NT == 1 ? 4 : 3;
+    static constexpr int NBUF = (NT == 1 && CB == 1) ? 4 : 3;
 };
 
 template <int N> __device__ __forceinline__ void tg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -65,15 +69,17 @@ __device__ __forceinline__ int tg_sload(const int32_t* p) {
     return v;
 }
 
-template <int NT>
+template <int NT, int CB = 1>
 __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char* smem, int tile_n, int tile_c, int tap0, int split) {
     static_assert(NT >= 1 && NT <= 5, "tap group of 1 .. 5 taps");
+    static_assert(CB == 1 || (CB == 2 && NT == 1), "two X images only for one-tap launches");
+    constexpr int XI = TgCfg<NT, CB>::X_BYTES;
     constexpr int NR = (8 + NT - 1 + 3) / 4;             // transposing reads per X run (4 rows each): 2 (NT = 1) or 3
-    constexpr int TG_X_ROWS = TgCfg<NT>::X_ROWS, TG_BUF_BYTES = TgCfg<NT>::BUF_BYTES, NBUF = TgCfg<NT>::NBUF, D = NBUF - 1;
+    constexpr int TG_X_ROWS = TgCfg<NT, CB>::X_ROWS, TG_BUF_BYTES = TgCfg<NT, CB>::BUF_BYTES, NBUF = TgCfg<NT, CB>::NBUF, D = NBUF - 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // 8 waves: wm = n half, wn = 32-column block of c
     const int wm = wave >> 2, wn = wave & 3;
-    const int n0 = tile_n * 128, c0 = tile_c * 128;
+    const int n0 = tile_n * 128, c0 = tile_c * 128 * CB;
     const int shift0 = tap0 - a.pad;                     // tile row r of the X image = sequence row t0 + shift0 + r (dil == 1)
     const int tps = (a.S + 63) >> 6;                     // K-tiles per sequence
     const int nunits = (a.M / a.S) * tps;
@@ -105,6 +111,7 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
     const int cg = (((lq >> 2) ^ lrow) << 2) | (lq & 3);
     const unsigned acol_b = (unsigned)min(n0 + cg * 8, a.N - 8) * 2u;    // clamped into the matrix (tails feed outputs nobody stores)
     const unsigned xcol_b = (unsigned)min(c0 + cg * 8, a.Cin - 8) * 2u;
+    const unsigned xcol_b2 = (unsigned)min(c0 + 128 + cg * 8, a.Cin - 8) * 2u;        // (CB == 2: the second 128-column image)
     const unsigned dy_rs = (unsigned)a.lddy * 2u, x_rs = (unsigned)a.ldx * 2u;
     const bool w5 = TG_X_ROWS > 64 && wave < 2;         // (NT == 1: no halo pieces, 4 pieces per wave)
     auto issue = [&](const TgUnit& q, int buf) {
@@ -120,6 +127,7 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
         for (int i = 0; i < 2; ++i) {
             const int t = min(max(t0 + shift0 + 4 * wave + 32 * i + lrow, 0), a.S - 1);
             glds16_sbase((base + (unsigned)t) * x_rs + xcol_b, a.X, dst + (unsigned)(TG_A_BYTES + i * 8192));
+            if (CB == 2) glds16_sbase((base + (unsigned)t) * x_rs + xcol_b2, a.X, dst + (unsigned)(TG_A_BYTES + XI + i * 8192));
         }
         if (w5) {
             const int t = min(max(t0 + shift0 + 64 + 4 * wave + lrow, 0), a.S - 1);
@@ -142,9 +150,9 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
     typedef __attribute__((address_space(3))) tg_s16x4* lds_s4;
     auto tr_read = [&](unsigned off) -> tg_s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(size_t)(smem_u + off)); };
 
-    f32x16 acc[NT][2];
+    f32x16 acc[NT * CB][2];                              // (CB == 2, one tap: [X image][n block])
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT * CB; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -153,7 +161,7 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
     float bsum[2] = {0.f, 0.f};
 
     tg_u32x4 af[2][2];                                   // [set][n block]: fragment double buffer over the 16-row sub-steps
-    tg_u32x2 run[2][NR];                                 // [set][read]: rows 8h + 4q .. + 3 of the lane's X column as two row-pair dwords
+    tg_u32x2 run[2][CB][NR];                             // [set][X image][read]: rows 8h + 4q .. + 3 of the lane's X column as two row-pair dwords
     // one K-tile out of LDS buffer BUF (compile time: every ds_read offset is an immediate)
     auto ktile = [&](auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
@@ -166,13 +174,15 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
                 af[set][blk] = __builtin_bit_cast(tg_u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
-            for (int r = 0; r < NR; ++r) run[set][r] = __builtin_bit_cast(tg_u32x2, tr_read(offB + bufoff + ks * 4096 + r * 1024));
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) run[set][cb][r] = __builtin_bit_cast(tg_u32x2, tr_read(offB + bufoff + cb * XI + ks * 4096 + r * 1024));
         };
         auto mma = [&](int set) {
             const tg_u32x4 av[2] = {af[set][0], af[set][1]};
             unsigned R[2 * NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) { R[2 * r] = run[set][r][0]; R[2 * r + 1] = run[set][r][1]; }
+            for (int r = 0; r < NR; ++r) { R[2 * r] = run[set][0][r][0]; R[2 * r + 1] = run[set][0][r][1]; }
             if (do_bias) {
                 // (each dword goes through a named scalar: written as av[blk][d] inside the bit_cast, hipcc 7.2 fed element 0 to all
                 // four v_dot2c - seen in the ISA and as an O(1)-wrong bias gradient on the first GPU run)
@@ -201,6 +211,14 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
                 for (int mb = 0; mb < 2; ++mb)
                     acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]), __builtin_bit_cast(bf16x8, b),
                                                                          acc[t][mb], 0, 0, 0);
+            }
+            if constexpr (CB == 2) {                     // the second X image against the same dY fragments
+                tg_u32x4 b2;
+                b2[0] = run[set][1][0][0]; b2[1] = run[set][1][0][1]; b2[2] = run[set][1][1][0]; b2[3] = run[set][1][1][1];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[1][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mb]), __builtin_bit_cast(bf16x8, b2),
+                                                                         acc[1][mb], 0, 0, 0);
             }
         };
         read_frags(0, 0);
@@ -235,7 +253,10 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
             // partner row is beyond the valid part (a zero) - and 0 x whatever the producer left in a padded row (attention
             // output, skipped tiles: possibly NaN bit patterns) must stay 0, so those rows are zeroed too
             const int rx = 4 * wave + 32 * i + lrow, tx = t0 + shift0 + rx;
-            if (tx < 0 || tx >= a.S || rx >= xdead) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + i * 8192) = z;
+            if (tx < 0 || tx >= a.S || rx >= xdead) {
+                *reinterpret_cast<uint4*>(bp + TG_A_BYTES + i * 8192) = z;
+                if (CB == 2) *reinterpret_cast<uint4*>(bp + TG_A_BYTES + XI + i * 8192) = z;
+            }
         }
         if (w5) {
             const int rx = 64 + 4 * wave + lrow, tx = t0 + shift0 + rx;
@@ -248,10 +269,11 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
         int ahead = 0;                                    // tiles issued after q[0] whose pieces may stay in flight
 #pragma unroll
         for (int i = 1; i < D; ++i) ahead += (q[i].u < uend) ? 1 : 0;
+        constexpr int P = 2 + 2 * CB;                     // DMA pieces per wave and tile (+ 1 halo piece on waves 0, 1 of a multi-tap tile)
         if (ahead == 0) tg_wait_vm<0>();
-        else if (ahead == 1) { if (w5) tg_wait_vm<5>(); else tg_wait_vm<4>(); }
-        else if (ahead == 2) { if (w5) tg_wait_vm<10>(); else tg_wait_vm<8>(); }
-        else { if (w5) tg_wait_vm<15>(); else tg_wait_vm<12>(); }
+        else if (ahead == 1) { if (w5) tg_wait_vm<P + 1>(); else tg_wait_vm<P>(); }
+        else if (ahead == 2) { if (w5) tg_wait_vm<2 * P + 2>(); else tg_wait_vm<2 * P>(); }
+        else { if (w5) tg_wait_vm<3 * P + 3>(); else tg_wait_vm<3 * P>(); }
         const int t0 = q[0].j * 64;
         if ((t0 + 64 > q[0].tend) || (t0 + shift0 < 0) || (t0 + shift0 + TG_X_ROWS > a.S)) zero_rows(q[0], BUF);   // (block-uniform)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,6 +327,12 @@ __device__ __forceinline__ void wgrad_tg_body(const WgradArgs& a, unsigned char*
 #pragma unroll
                     for (int t = 0; t < NT; ++t) atomicAdd(dst + (size_t)t * a.Cin, acc[t][mb][r]);
                 }
+                if constexpr (CB == 2) {                  // the second X image: columns c + 128 (one tap)
+                    if (c + 128 < a.Cin) {
+                        if (a.slab) dst[128] = acc[1][mb][r];
+                        else atomicAdd(dst + 128, acc[1][mb][r]);
+                    }
+                }
             }
     }
 }
@@ -334,6 +362,30 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad_tg_kernel(WgradArgs a) {
     else wgrad_tg_body<(NR ? NR : 1)>(a, smem, tile_n, tile_c, a.g3 * NF, split);
 }
 
+// one tap, 128 (n) x 256 (c) workgroup tiles (TgCfg<1, 2>: three 48 KiB buffers)
+__global__ void __launch_bounds__(512, 2) conv_wgrad_tg1w_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ntn = (a.N + 127) >> 7, ntc = (a.Cin + 255) >> 8;
+    const int kx = blockIdx.x >> 3;
+    const int pair = (int)(blockIdx.x & 7) * a.per_xcd + kx;
+    if (pair >= a.n_tiles * a.n_splits) return;
+    const int split = pair / a.n_tiles;
+    int bx = pair - split * a.n_tiles;
+    const int tile_n = bx % ntn; bx /= ntn;
+    const int tile_c = bx % ntc;
+    wgrad_tg_body<1, 2>(a, smem, tile_n, tile_c, 0, split);
+}
+static void launch_tg1w(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
+    constexpr int dyn = TgCfg<1, 2>::NBUF * TgCfg<1, 2>::BUF_BYTES;
+    static Fs2DevOnce once;
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_wgrad_tg1w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); });
+    a.g3 = p.g_first;
+    a.rows_per_split = p.ups;
+    a.n_tiles = p.tiles; a.n_splits = p.splits;
+    a.per_xcd = (p.tiles * p.splits + 7) / 8;
+    conv_wgrad_tg1w_kernel<<<dim3((unsigned)(8 * a.per_xcd)), 512, dyn, stream>>>(a);
+}
+
 template <int NF, int NR>
 static void launch_tg(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
     constexpr int dyn = (TgCfg<NF>::NBUF * TgCfg<NF>::BUF_BYTES > TgCfg<(NR ? NR : NF)>::NBUF * TgCfg<(NR ? NR : NF)>::BUF_BYTES)
@@ -349,6 +401,7 @@ static void launch_tg(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
 
 bool fs2_wgrad_tg_launch(WgradArgs a, const WgradPlan& p, hipStream_t stream) {
     const int nf = p.n_first, nr = p.n_rest;
+    if (p.share == 2 && nf == 1 && nr == 0) { launch_tg1w(a, p, stream); return true; }     // (the caller counted 128 x 256 tiles)
     if (nf == 5 && nr == 0) launch_tg<5, 0>(a, p, stream);
     else if (nf == 5 && nr == 4) launch_tg<5, 4>(a, p, stream);
     else if (nf == 4 && nr == 0) launch_tg<4, 0>(a, p, stream);
