@@ -190,7 +190,9 @@ __device__ __forceinline__ bf16x8 pack8(const float* p) {
     v.x = pack_bf16x2(p[0], p[1]); v.y = pack_bf16x2(p[2], p[3]); v.z = pack_bf16x2(p[4], p[5]); v.w = pack_bf16x2(p[6], p[7]);
     return __builtin_bit_cast(bf16x8, v);
 }
-// load this lane's K-contiguous register fragments of one row (8 steps x 8 bf16), optionally scaled
+// load this lane's K-contiguous register fragments of one row (8 steps x 8 bf16), optionally scaled.  (Round 6 measured the alternative - the
+// 128 rows read row-wise in full lines, parked in a free LDS image, fragments by ds_read_b128: the dQ prologue is 15 000 cycles either
+// way (tools/attn_phases.py 1): a workgroup's cold start is a memory round trip under a whole-chip burst, not a coalescing problem)
 __device__ __forceinline__ void load_row_frags(bf16x8* f, const bf16_t* row, int h, bool ok) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -225,10 +227,12 @@ extern "C" int fs2_dev_attn_stamps(unsigned long long* out) {
 #define FS2_STAMP_INIT() const bool fs2_stamp_on = fs2_attn_stamp_kernel == FS2_STAMP_KERNEL && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0
 #define FS2_STAMP_AT(t0_, i) do { if (fs2_stamp_on && (t0_) < 16 * 64) fs2_attn_stamps[((t0_) >> 6) * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define FS2_STAMP(i) FS2_STAMP_AT(q0, i)
+#define FS2_STAMP_RAW(i) do { if (fs2_stamp_on) fs2_attn_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FS2_STAMP_INIT() do {} while (0)
 #define FS2_STAMP_AT(t0_, i) do {} while (0)
 #define FS2_STAMP(i) do {} while (0)
+#define FS2_STAMP_RAW(i) do {} while (0)
 #endif
 
 // XCD-AWARE BLOCK MAP (round 6).  The grid is (tiles, H, B) and the dispatcher deals consecutive workgroups round-robin to the 8
@@ -251,7 +255,8 @@ __device__ __forceinline__ void attn_block_map(int H, int& t, int& h, int& b) {
 // lane's pieces in the CURRENT buffer's first image; the second image (+16 KiB), the 32-row block (+8 KiB) and the 16-row group of a
 // transposing read (+4 KiB) enter as immediate offsets, and flip() moves all of them to the other buffer (+-32 KiB) once per tile.
 // The first form recomputed swzb() for every read: ~80 of a tile's ~240 vector instructions in the forward kernel.
-struct FragAddr {
+// IMG: bytes of one tile image (64 rows x 256 B = 16 KiB; 8 KiB in the 32-key-tile kernels); NTHR: threads of the workgroup
+template <int IMG, int NTHR> struct FragAddrT {
     unsigned k[8], t0[4], t1[4], st[4];
     int step;
     __device__ __forceinline__ void init(unsigned base, int tid) {
@@ -266,8 +271,8 @@ struct FragAddr {
             t1[nb] = base + (unsigned)(swzb(rr + 8, col >> 3) + ((col & 7) << 1));
         }
 #pragma unroll
-        for (int I = 0; I < 4; ++I) st[I] = base + 32768u + (unsigned)swzb((tid + 256 * I) >> 4, tid & 15);   // stores go to the OTHER buffer
-        step = 32768;
+        for (int I = 0; I < 4; ++I) st[I] = base + (unsigned)(2 * IMG) + (unsigned)swzb((tid + NTHR * I) >> 4, tid & 15);   // stores go to the OTHER buffer
+        step = 2 * IMG;
     }
     __device__ __forceinline__ void flip() {
 #pragma unroll
@@ -282,12 +287,12 @@ struct FragAddr {
     __device__ __forceinline__ bf16x8 rk(int img, int blk, int i) const {
         typedef unsigned lds_v4u __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) const lds_v4u* lds_u4p;
-        return __builtin_bit_cast(bf16x8, *(lds_u4p)(size_t)(k[i] + (unsigned)(img * 16384 + blk * 8192)));
+        return __builtin_bit_cast(bf16x8, *(lds_u4p)(size_t)(k[i] + (unsigned)(img * IMG + blk * 8192)));
     }
     // transposed fragment: image img, rows rb .. rb + 15 (rb a multiple of 16), column block nb
     __device__ __forceinline__ bf16x8 rt(int img, int rb, int nb) const {
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(t0[nb] + (unsigned)(img * 16384 + rb * 256)));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(t1[nb] + (unsigned)(img * 16384 + rb * 256)));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(t0[nb] + (unsigned)(img * IMG + rb * 256)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(size_t)(t1[nb] + (unsigned)(img * IMG + rb * 256)));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
     // register-staged tile store into the other buffer's image img
@@ -295,12 +300,13 @@ struct FragAddr {
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef unsigned lds_v4u __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) lds_v4u* lds_u4w;
-        *(lds_u4w)(size_t)(st[I] + (unsigned)(img * 16384)) = lds_v4u{v.x, v.y, v.z, v.w};
+        *(lds_u4w)(size_t)(st[I] + (unsigned)(img * IMG)) = lds_v4u{v.x, v.y, v.z, v.w};
 #else
         (void)img; (void)v; (void)I;
 #endif
     }
 };
+typedef FragAddrT<16384, 256> FragAddr;                  // 64-row tile images, 256-thread workgroups
 #define TILE_STORE_FA(fa, img, t) do { (fa).store(img, t##0, 0); (fa).store(img, t##1, 1); (fa).store(img, t##2, 2); (fa).store(img, t##3, 3); } while (0)
 
 
@@ -496,6 +502,12 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(const bf16_t* __r
     attn_store_row(out + (size_t)min(myq, S - 1) * ldo, o, linv, h2, myq < S);
 }
 #undef FS2_STAMP_KERNEL
+
+// (Round 6 measured a SMALL-ITEM forward - 64 queries per two-wave workgroup, 32-key tiles, 32 KiB of LDS, four workgroups per CU - to
+// even out the dealing of ~660 live items over the CU slots (a launch lasts two item lives for 1.3 items per slot): parity green, 70 us
+// against 65 (profiles/r06xc_bench_attn.log).  Every K / V tile is staged by twice as many workgroups, there is a barrier per 32 keys and
+// twice as many ~15 000-cycle cold starts: the per-item loss outweighs the better dealing.  Not kept; git history has the kernel.)
+
 // dK, dV: one wave owns 32 keys (K, V fragments in registers); the block streams 64-query tiles of Q / dO.
 // Per tile the log-sum-exp and delta values of its 64 queries travel with the Q / dO prefetch into LDS: the first
 // version fetched them from GLOBAL memory element by element inside the `key_ok && q < len` branch - 32 dependent,
@@ -963,6 +975,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_dkv2_bf16_kernel(const bf16_t
 #undef FS2_STAMP_KERNEL
 // (also computes delta[q] = sum_d dO[q][d] O[q][d] for its queries - a lane already holds half of its query's dO row - and
 // writes it for the dK/dV kernel, which therefore runs AFTER this one: the separate delta launch, 12 us per layer, is gone)
+#define FS2_STAMP_KERNEL 1
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                                   const bf16_t* __restrict__ ctx,
                                                                   const bf16_t* __restrict__ dctx, long ldo,
@@ -971,6 +984,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                                                                   int S, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char sKV[2][2][64 * 256];   // [buffer][K | V]
     FS2_ATTN_PRIO_INIT();
+    FS2_STAMP_INIT();
+    FS2_STAMP_RAW(0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fl = lane & 31, h2 = lane >> 5;
     int qt, h, b;
     attn_block_map(H, qt, h, b);
@@ -1031,12 +1046,15 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
     __syncthreads();
     FragAddr fa;
     fa.init(lds_addr(&sKV[0][0][0]), tid);
+    FS2_STAMP_RAW(1);
     for (int k0 = 0; k0 < len; k0 += 64) {
         const bool more = k0 + 64 < len;
+        FS2_STAMP_AT(k0 + 64, 0);
         if (more) {
             TILE_LOAD_REGS(tk, K, ld, k0 + 64, S - 1);
             TILE_LOAD_REGS(tv, V, ld, k0 + 64, S - 1);
         }
+        FS2_STAMP_AT(k0 + 64, 1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (k0 + kb * 32 >= len) break;
@@ -1060,6 +1078,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 }
                 FS2_ATTN_PRIO(0);
             }
+            FS2_STAMP_AT(k0 + 64, 2 + 3 * kb);
             float dsv[16];
             // the only key block with padded keys gets its scores masked BEFORE the exponential, behind a wave-uniform branch (as a
             // per-element select in the common loop it was 94 of the loop's 310 VALU instructions: r03m instruction mix)
@@ -1075,6 +1094,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, -my_lse2));
                 dsv[r] = p * (dp[r] - my_del);                                  // (the softmax scale multiplies dQ once, at the store)
             }
+            FS2_STAMP_AT(k0 + 64, 3 + 3 * kb);
             FS2_ATTN_PRIO(1);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1084,16 +1104,20 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_bf16_kernel(const bf16_t* 
                     dq[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rt(0, kb * 32 + 16 * u, nb), da, dq[nb], 0, 0, 0);       // dQ^T[d][q] += K^T dS^T
             }
             FS2_ATTN_PRIO(0);
+            FS2_STAMP_AT(k0 + 64, 4 + 3 * kb);
         }
         if (more) {
             TILE_STORE_FA(fa, 0, tk);
             TILE_STORE_FA(fa, 1, tv);
         }
         fa.flip();
+        FS2_STAMP_AT(k0 + 64, 8);
         __syncthreads();
+        FS2_STAMP_AT(k0 + 64, 9);
     }
     attn_store_row(dQ + (size_t)min(myq, S - 1) * ld, dq, scale, h2, myq < S);
 }
+#undef FS2_STAMP_KERNEL
 
 extern "C" int fs2_attn_fwd(const void* qkv, void* ctx, float* lse, const int32_t* lens, int B, int S, int H, int dk,
                             float scale, int dtype, hipStream_t stream) {

@@ -24,6 +24,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (16 * 12))()
 assert lib.fs2_dev_attn_stamps(buf) == 0
+if which == 1:
+    print(f"dQ kernel: prologue (Q / dO / O rows, delta) {buf[1] - buf[0]} cycles")
+    names = ["prefetch issue", "S,dP kb0", "softmax kb0", "dQ kb0", "S,dP kb1", "softmax kb1", "dQ kb1", "store+flip", "barrier"]
+    print("tile " + " ".join(f"{n:>14s}" for n in names) + "       total")
+    for t in range(2, 9):
+        st = [buf[t * 12 + i] for i in range(10)]
+        if st[9] == 0: break
+        print(f"{t - 1:4d} " + " ".join(f"{st[i + 1] - st[i]:14d}" for i in range(9)) + f" {st[9] - st[0]:11d}")
+    sys.exit(0)
 if which == 0:
     names = ["prefetch issue", "QK^T", "softmax", "PV", "store", "barrier"]
     print("tile " + " ".join(f"{n:>14s}" for n in names) + "       total")
